@@ -1,0 +1,156 @@
+"""ctypes binding of the CPU oracle (oracle/sasa_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under rustsasa_amd/ may import this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libsasa_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (oracle/Makefile) if missing or stale."""
+    src = [os.path.join(_HERE, f) for f in ("sasa_oracle.c", "sasa_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in src
+    )
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "libsasa_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class _NeighborLists(C.Structure):
+    _fields_ = [("n_atoms", C.c_size_t), ("offsets", C.POINTER(C.c_size_t)),
+                ("entries", C.c_void_p)]
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        build()
+        lib = C.CDLL(_SO)
+        fp = C.POINTER(C.c_float)
+        u32p = C.POINTER(C.c_uint32)
+        u64p = C.POINTER(C.c_uint64)
+        lib.oracle_generate_sphere_points.argtypes = [C.c_size_t, fp, fp, fp]
+        lib.oracle_generate_sphere_points.restype = None
+        lib.oracle_calculate_sasa_internal.argtypes = [fp, fp, fp, fp, u64p, C.c_size_t, C.c_float,
+                                                       C.c_size_t, C.c_int, fp, u32p, u32p]
+        lib.oracle_calculate_sasa_internal.restype = C.c_int
+        lib.oracle_calculate_sasa_batch.argtypes = [fp, fp, fp, fp, u64p, u32p, C.c_size_t,
+                                                    C.c_float, C.c_size_t, C.c_int, C.c_int, fp]
+        lib.oracle_calculate_sasa_batch.restype = C.c_int
+        lib.oracle_neighbor_lists.argtypes = [fp, fp, fp, fp, u64p, C.c_size_t, C.c_float,
+                                              C.c_float, C.c_float, C.c_float,
+                                              C.POINTER(_NeighborLists)]
+        lib.oracle_neighbor_lists.restype = C.c_int
+        lib.oracle_neighbor_lists_free.argtypes = [C.POINTER(_NeighborLists)]
+        lib.oracle_neighbor_lists_free.restype = None
+        lib.oracle_residue_sums.argtypes = [fp, u32p, C.c_size_t, fp]
+        lib.oracle_residue_sums.restype = None
+        lib.oracle_max_threads.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a, ty):
+    return a.ctypes.data_as(C.POINTER(ty)) if a is not None else None
+
+
+def sphere_points(n_points: int):
+    x = np.empty(n_points, np.float32)
+    y = np.empty(n_points, np.float32)
+    z = np.empty(n_points, np.float32)
+    _load().oracle_generate_sphere_points(n_points, _ptr(x, C.c_float), _ptr(y, C.c_float),
+                                          _ptr(z, C.c_float))
+    return x, y, z
+
+
+def calculate_sasa_internal(x, y, z, radius, ids=None, probe_radius=1.4, n_points=100,
+                            simd_width=8, return_details=False):
+    """Restatement of calculate_sasa_internal (reference src/lib.rs:249-298)."""
+    x, y, z, radius = map(_f32, (x, y, z, radius))
+    n = x.shape[0]
+    ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    out = np.zeros(n, np.float32)
+    pts = np.zeros(n, np.uint32)
+    k = np.zeros(n, np.uint32)
+    rc = _load().oracle_calculate_sasa_internal(
+        _ptr(x, C.c_float), _ptr(y, C.c_float), _ptr(z, C.c_float), _ptr(radius, C.c_float),
+        _ptr(ids_a, C.c_uint64), n, np.float32(probe_radius), n_points, simd_width,
+        _ptr(out, C.c_float), _ptr(pts, C.c_uint32), _ptr(k, C.c_uint32))
+    if rc != 0:
+        raise RuntimeError(f"oracle_calculate_sasa_internal failed ({rc})")
+    if return_details:
+        return out, pts, k
+    return out
+
+
+def calculate_sasa_batch(x, y, z, radius, ids, offsets, probe_radius=1.4, n_points=100,
+                         simd_width=8, threads=1):
+    x, y, z, radius = map(_f32, (x, y, z, radius))
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+    ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    out = np.zeros(x.shape[0], np.float32)
+    rc = _load().oracle_calculate_sasa_batch(
+        _ptr(x, C.c_float), _ptr(y, C.c_float), _ptr(z, C.c_float), _ptr(radius, C.c_float),
+        _ptr(ids_a, C.c_uint64), _ptr(offsets, C.c_uint32), offsets.shape[0] - 1,
+        np.float32(probe_radius), n_points, simd_width, threads, _ptr(out, C.c_float))
+    if rc != 0:
+        raise RuntimeError(f"oracle_calculate_sasa_batch failed ({rc})")
+    return out
+
+
+def neighbor_lists(x, y, z, radius, ids=None, probe_radius=1.4, max_radius=None, cell_size=0.0,
+                   max_search_radius=0.0):
+    """Per-atom neighbour lists [(idx, threshold_squared), ...] (spatial_grid.rs:195-278)."""
+    x, y, z, radius = map(_f32, (x, y, z, radius))
+    n = x.shape[0]
+    if max_radius is None:
+        max_radius = float(np.max(radius, initial=np.float32(0.0)))
+    ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    nl = _NeighborLists()
+    rc = _load().oracle_neighbor_lists(
+        _ptr(x, C.c_float), _ptr(y, C.c_float), _ptr(z, C.c_float), _ptr(radius, C.c_float),
+        _ptr(ids_a, C.c_uint64), n, np.float32(probe_radius), np.float32(max_radius),
+        np.float32(cell_size), np.float32(max_search_radius), C.byref(nl))
+    if rc != 0:
+        raise RuntimeError("oracle_neighbor_lists failed")
+    try:
+        offs = np.ctypeslib.as_array(nl.offsets, shape=(n + 1,)).copy()
+        total = int(offs[-1])
+        dt = np.dtype([("threshold_squared", np.float32), ("idx", np.uint32)])
+        if total:
+            buf = (C.c_char * (total * dt.itemsize)).from_address(nl.entries)
+            ent = np.frombuffer(buf, dtype=dt).copy()
+        else:
+            ent = np.zeros(0, dt)
+    finally:
+        _load().oracle_neighbor_lists_free(C.byref(nl))
+    return [ent[offs[i]:offs[i + 1]] for i in range(n)]
+
+
+def residue_sums(atom_sasa, residue_offsets):
+    atom_sasa = _f32(atom_sasa)
+    residue_offsets = np.ascontiguousarray(residue_offsets, dtype=np.uint32)
+    out = np.zeros(residue_offsets.shape[0] - 1, np.float32)
+    _load().oracle_residue_sums(_ptr(atom_sasa, C.c_float), _ptr(residue_offsets, C.c_uint32),
+                                out.shape[0], _ptr(out, C.c_float))
+    return out
+
+
+def max_threads() -> int:
+    return int(_load().oracle_max_threads())

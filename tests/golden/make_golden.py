@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Regenerates the golden fixtures under tests/golden/ from the reference tree.
+
+Run in the build container only (needs /root/reference, which does not exist
+on the GPU box).  Fixtures are DATA: the reference's own test inputs
+(tests/data/...) and the numeric literals of its golden vector
+FIXED_LOW_RES_ATOMS (tests/common/data.rs:4-238), written one value per line.
+No reference source text is stored.
+"""
+import os
+import re
+import shutil
+import sys
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+DATA_FILES = [
+    "tests/data/pdbs/example.cif",
+    "tests/data/pdbs/151L_H3.pdb",
+    "tests/data/pdbs/bad_seqadv_1A06.pdb",
+    "tests/data/freesasa_pdbs/1jcd.pdb",
+    "tests/data/freesasa_pdbs/2drt.pdb",   # small clean multi-chain file with HETATM
+]
+
+
+def main():
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    for rel in DATA_FILES:
+        dst = os.path.join(HERE, "data", os.path.basename(rel))
+        shutil.copyfile(os.path.join(REF, rel), dst)
+        os.chmod(dst, 0o644)
+
+    text = open(os.path.join(REF, "tests/common/data.rs")).read()
+    m = re.search(r"FIXED_LOW_RES_ATOMS:\s*\[f32;\s*(\d+)\]\s*=\s*\[(.*?)\];", text, re.S)
+    n = int(m.group(1))
+    vals = [v.strip() for v in m.group(2).replace("\n", " ").split(",") if v.strip()]
+    assert len(vals) == n == 2622, (len(vals), n)
+    with open(os.path.join(HERE, "fixed_low_res_atoms.txt"), "w") as f:
+        f.write("# FIXED_LOW_RES_ATOMS (reference tests/common/data.rs:4-238): per-atom SASA,\n"
+                "# example.cif, pdbtbx van-der-Waals radii, ids = serials, probe 1.4, 100 points\n")
+        f.write("\n".join(vals) + "\n")
+    print(f"wrote {n} golden values and {len(DATA_FILES)} data files")
+
+
+if __name__ == "__main__":
+    main()
