@@ -1,0 +1,165 @@
+/*
+ * rustsasa_amd.h -- C ABI of the MI355X-native Shrake-Rupley SASA engine.
+ *
+ * This is the drop-in boundary for RustSASA's hot path.  The reference has no
+ * FFI layer of its own; its seam is the free function
+ *
+ *     pub fn calculate_sasa_internal(atoms: &[Atom], probe_radius: f32,
+ *                                    n_points: usize, threads: isize) -> Vec<f32>
+ *                                                     (reference src/lib.rs:249-254)
+ *
+ * called from SASAOptions::<T>::process (reference src/options.rs:615-616).
+ * Every entry point below cites the reference interface it replaces.  The
+ * Rust-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function
+ * returns RSASA_OK (0) or a negative rsasa_status; nothing throws across the
+ * boundary; all `out_*` buffers are caller-owned.  The library is built for
+ * gfx950 only and has NO CPU fallback: without a usable HIP device every
+ * compute entry point fails with RSASA_ERR_NO_DEVICE.
+ */
+#ifndef RUSTSASA_AMD_H
+#define RUSTSASA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSASA_ABI_VERSION 1
+
+typedef enum rsasa_status {
+    RSASA_OK = 0,
+    RSASA_ERR_INVALID_ARGUMENT = -1, /* NULL where data is required, probe+max_radius <= 0, n_points == 0, ... */
+    RSASA_ERR_NO_DEVICE = -2,        /* no HIP device / device index out of range */
+    RSASA_ERR_HIP = -3,              /* a HIP runtime call failed; see rsasa_context_last_error */
+    RSASA_ERR_OUT_OF_MEMORY = -4,
+    RSASA_ERR_GRID_TOO_LARGE = -5,   /* a structure's cell grid exceeds 2^31 cells (coordinates too sparse) */
+    RSASA_ERR_INTERNAL = -6
+} rsasa_status;
+
+/* Mirrors `Atom` (reference src/structures/atomic.rs:13-24) without the
+ * parent_id field, which the hot path never reads.  24 bytes, C layout. */
+typedef struct rsasa_atom {
+    float position[3];
+    float radius;
+    uint64_t id; /* atoms with equal id never occlude each other (src/lib.rs:124) */
+} rsasa_atom_t;
+
+typedef struct rsasa_context rsasa_context_t;
+
+/* ---- library / device ------------------------------------------------- */
+int rsasa_abi_version(void);
+const char *rsasa_status_string(int status);
+/* Number of HIP devices visible to this process (0 is a valid answer). */
+int rsasa_device_count(int *out_count);
+
+/* One context = one GPU + one HIP stream + a growable HBM workspace and a
+ * cached sphere lattice.  Calls on one context are serialised by an internal
+ * mutex; use one context per host thread (or per rayon worker) for
+ * concurrency.  Replaces the reference's global rayon pool
+ * (src/utils.rs:63-81) as the unit of parallel resources. */
+int rsasa_context_create(int device, rsasa_context_t **out_ctx);
+int rsasa_context_destroy(rsasa_context_t *ctx);
+const char *rsasa_context_last_error(const rsasa_context_t *ctx);
+
+/* pulp lane count W the reference host would dispatch to (8 = AVX2+FMA
+ * [default], 16 = AVX-512, 4 = NEON, 1 = scalar).  It only selects which of
+ * the last (n_points mod W) sphere points use the reference's scalar
+ * remainder rule -- unfused dot product and `<=` (src/lib.rs:163-218). */
+int rsasa_context_set_simd_width(rsasa_context_t *ctx, int simd_width);
+
+/* ---- the hot path, one structure per call ------------------------------ */
+
+/* Drop-in for calculate_sasa_internal (reference src/lib.rs:249-254).
+ * `threads` is accepted for signature compatibility and ignored (the
+ * reference uses it only to choose sequential vs rayon, src/lib.rs:278).
+ * out_sasa[i] is the SASA of atoms[i] in A^2; n_atoms == 0 is valid. */
+int rsasa_calculate_sasa_internal(rsasa_context_t *ctx, const rsasa_atom_t *atoms,
+                                  size_t n_atoms, float probe_radius, size_t n_points,
+                                  ptrdiff_t threads, float *out_sasa);
+
+/* Same computation on struct-of-arrays input.  `id` may be NULL (all atoms
+ * distinct). */
+int rsasa_calculate_sasa_soa(rsasa_context_t *ctx, const float *x, const float *y,
+                             const float *z, const float *radius, const uint64_t *id,
+                             size_t n_atoms, float probe_radius, size_t n_points,
+                             float *out_sasa);
+
+/* ---- the hot path, many structures per call ---------------------------- */
+
+/* Directory mode (reference src/main.rs:375,439): n_structures independent
+ * structures concatenated into one SoA; structure s owns atoms
+ * [structure_offsets[s], structure_offsets[s+1]).  Each structure gets its
+ * own bounding box, cell grid and max radius exactly as a separate
+ * calculate_sasa_internal call would.
+ *
+ * Optional ResidueLevel aggregation (reference src/options.rs:202-216,
+ * src/utils.rs:14-22): residue k owns atoms
+ * [residue_offsets[k], residue_offsets[k+1]) of the concatenated arrays and
+ * out_residue_sasa[k] is their strictly sequential f32 sum.  Pass
+ * residue_offsets = NULL / n_residues = 0 to skip.  out_atom_sasa may be NULL
+ * when only residue values are wanted.  All pointers are HOST pointers. */
+int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float *y,
+                               const float *z, const float *radius, const uint64_t *id,
+                               const uint32_t *structure_offsets, size_t n_structures,
+                               float probe_radius, size_t n_points, float *out_atom_sasa,
+                               const uint32_t *residue_offsets, size_t n_residues,
+                               float *out_residue_sasa);
+
+/* Device-resident form of the batch call: every pointer in the descriptor is
+ * a DEVICE pointer on the context's GPU except structure_offsets_host, which
+ * stays on the host (the launch geometry is derived from it).  The call only
+ * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own
+ * stream) and returns; rsasa_batch_wait() synchronises, reports deferred
+ * errors and transparently re-runs the batch if the cell workspace had to
+ * grow.  Buffers must stay valid until rsasa_batch_wait returns. */
+typedef struct rsasa_device_batch {
+    const float *x, *y, *z, *radius;       /* [n_atoms] device */
+    const uint64_t *id;                    /* [n_atoms] device, or NULL */
+    const uint32_t *structure_offsets_host;/* [n_structures + 1] HOST */
+    size_t n_structures;
+    size_t n_atoms;
+    const uint32_t *residue_offsets;       /* [n_residues + 1] device, or NULL */
+    size_t n_residues;
+    float *out_atom_sasa;                  /* [n_atoms] device, or NULL */
+    float *out_residue_sasa;               /* [n_residues] device, or NULL */
+    uint32_t *out_neighbor_counts;         /* [n_atoms] device, or NULL: per-atom
+                                              candidate count K (the length of the
+                                              reference's neighbour list,
+                                              spatial_grid.rs:335-341) */
+} rsasa_device_batch_t;
+
+int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
+                        float probe_radius, size_t n_points, void *hip_stream);
+int rsasa_batch_wait(rsasa_context_t *ctx);
+
+/* ---- measurement ------------------------------------------------------- */
+
+/* When enabled, every rsasa_batch_enqueue brackets its kernels with HIP
+ * events on the launch stream; the elapsed times of the most recent
+ * completed batch are returned by rsasa_context_get_timings. */
+typedef struct rsasa_timings {
+    float grid_build_ms;   /* bounds + binning + scan + scatter kernels */
+    float occlusion_ms;    /* the occlusion kernel alone */
+    float aggregate_ms;    /* residue sums */
+    float total_ms;        /* first kernel start -> last kernel end */
+    uint64_t n_cells;      /* total grid cells of the batch */
+    uint64_t n_atoms;
+} rsasa_timings_t;
+
+int rsasa_context_enable_timing(rsasa_context_t *ctx, int enable);
+int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out);
+
+/* ---- utilities --------------------------------------------------------- */
+
+/* The golden-section-spiral lattice the engine uploads to the GPU
+ * (reference src/lib.rs:43-66), computed on the host with libm. */
+int rsasa_sphere_points(size_t n_points, float *out_x, float *out_y, float *out_z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTSASA_AMD_H */

@@ -1,0 +1,635 @@
+// C ABI of the engine (include/rustsasa_amd.h): contexts, HBM workspace,
+// sphere lattice cache, batch enqueue / wait.  Host code only; the kernels
+// live in kernels.hip.  There is no CPU compute path in this library.
+#include "../../include/rustsasa_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "device_types.h"
+
+namespace rsasa {
+
+// Golden-section spiral (reference src/lib.rs:43-66, constants
+// src/utils/consts.rs:18-19), f32 at every step, libm transcendentals.
+// Computed on the host and uploaded: the occlusion decision is integer valued,
+// so the table must be bit-identical to what the reference's host would use.
+void generate_sphere_points(size_t n, float *x, float *y, float *z)
+{
+    const float pi = 3.14159274101257324219f;
+    const float angle_increment = (2.0f * pi) * 1.618034f;
+    const float inv_n = 1.0f / (float)n;
+    for (size_t i = 0; i < n; i++) {
+        const float fi = (float)i;
+        const float t = fi * inv_n;
+        const float inclination = acosf(1.0f - 2.0f * t);
+        const float azimuth = angle_increment * fi;
+        const float si = sinf(inclination);
+        x[i] = si * cosf(azimuth);
+        y[i] = si * sinf(azimuth);
+        z[i] = cosf(inclination);
+    }
+}
+
+struct DeviceBuffer {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct LatticeEntry {
+    float *d = nullptr;  // x | y | z, each `padded` floats
+    uint32_t padded = 0;
+};
+
+struct Pending {
+    bool active = false;
+    rsasa_device_batch_t batch{};
+    float probe = 0.f;
+    size_t n_points = 0;
+    hipStream_t stream = nullptr;
+    int attempts = 0;
+};
+
+}  // namespace rsasa
+
+using namespace rsasa;
+
+struct rsasa_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::recursive_mutex mu;
+    std::string last_error;
+    int simd_width = 8;
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    rsasa_timings_t timings{};
+    bool timings_valid = false;
+
+    // workspace (device)
+    DeviceBuffer segments, acc, grids, sid, cell_of, rank_of, cells, scan_sums, sorted_xyzr,
+        sorted_orig, sorted_id, status, atom_sasa;
+    // staging for the host-pointer entry points (device)
+    DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
+    // pinned host
+    Segment *h_segments = nullptr;
+    size_t h_segments_cap = 0;
+    BatchStatus *h_status = nullptr;
+    uint64_t cell_capacity = 0;
+
+    std::map<std::pair<size_t, int>, LatticeEntry> lattices;
+    Pending pending;
+};
+
+namespace {
+
+int fail(rsasa_context *ctx, int code, const char *what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        ctx->last_error = what;
+        if (e != hipSuccess) {
+            ctx->last_error += ": ";
+            ctx->last_error += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+#define RS_HIP(ctx, expr)                                                           \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess)                                                       \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? RSASA_ERR_OUT_OF_MEMORY \
+                                                         : RSASA_ERR_HIP,           \
+                        #expr, e_);                                                 \
+    } while (0)
+
+// Grows `b` to at least `bytes` (contents are NOT preserved).  The caller has
+// already drained the stream if the buffer may be in use.
+int reserve(rsasa_context *ctx, DeviceBuffer &b, size_t bytes)
+{
+    if (bytes <= b.cap) return RSASA_OK;
+    if (b.p) {
+        RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RS_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        want = bytes;
+        e = hipMalloc(&b.p, want);
+    }
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "hipMalloc(workspace)", e);
+    }
+    b.cap = want;
+    return RSASA_OK;
+}
+
+void release(DeviceBuffer &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
+{
+    const auto key = std::make_pair(n_points, ctx->simd_width);
+    auto it = ctx->lattices.find(key);
+    if (it == ctx->lattices.end()) {
+        const uint32_t padded = (uint32_t)((n_points + 63) / 64 * 64);
+        std::vector<float> h(3 * (size_t)padded, 0.0f);
+        generate_sphere_points(n_points, h.data(), h.data() + padded, h.data() + 2 * (size_t)padded);
+        LatticeEntry e;
+        e.padded = padded;
+        RS_HIP(ctx, hipMalloc((void **)&e.d, h.size() * sizeof(float)));
+        hipError_t err = hipMemcpy(e.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            (void)hipFree(e.d);
+            return fail(ctx, RSASA_ERR_HIP, "hipMemcpy(lattice)", err);
+        }
+        it = ctx->lattices.emplace(key, e).first;
+    }
+    out->x = it->second.d;
+    out->y = it->second.d + it->second.padded;
+    out->z = it->second.d + 2 * (size_t)it->second.padded;
+    out->n_points = (uint32_t)n_points;
+    out->n_fused = (uint32_t)(n_points - n_points % (size_t)ctx->simd_width);
+    return RSASA_OK;
+}
+
+// Enqueues the whole pipeline for ctx->pending on its stream.
+int enqueue_pending(rsasa_context *ctx)
+{
+    Pending &pd = ctx->pending;
+    const rsasa_device_batch_t &bt = pd.batch;
+    const size_t N = bt.n_atoms, S = bt.n_structures, R = bt.n_residues;
+    hipStream_t st = pd.stream;
+
+    Lattice lat;
+    int rc = get_lattice(ctx, pd.n_points, &lat);
+    if (rc) return rc;
+
+    // bounds segments: <= kSegmentAtoms atoms of one structure each
+    size_t n_seg = 0;
+    for (size_t s = 0; s < S; s++) {
+        const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
+        n_seg += (e - b + kSegmentAtoms - 1) / kSegmentAtoms;
+    }
+    if (n_seg > ctx->h_segments_cap) {
+        if (ctx->h_segments) {
+            RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            RS_HIP(ctx, hipHostFree(ctx->h_segments));
+            ctx->h_segments = nullptr;
+            ctx->h_segments_cap = 0;
+        }
+        const size_t cap = n_seg + n_seg / 2 + 64;
+        RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_segments, cap * sizeof(Segment), hipHostMallocDefault));
+        ctx->h_segments_cap = cap;
+    }
+    {
+        size_t k = 0;
+        for (size_t s = 0; s < S; s++) {
+            const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
+            for (uint32_t a = b; a < e; a += kSegmentAtoms)
+                ctx->h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms)};
+        }
+    }
+
+    if (ctx->cell_capacity == 0)
+        ctx->cell_capacity = std::max<uint64_t>(1u << 16, 12ull * N + 64ull * S);
+    ctx->cell_capacity = std::min<uint64_t>(ctx->cell_capacity, 0xFFFFFFF0ull);
+
+    const bool has_id = bt.id != nullptr;
+    if ((rc = reserve(ctx, ctx->segments, std::max<size_t>(n_seg, 1) * sizeof(Segment)))) return rc;
+    if ((rc = reserve(ctx, ctx->acc, std::max<size_t>(S, 1) * sizeof(StructAcc)))) return rc;
+    if ((rc = reserve(ctx, ctx->grids, std::max<size_t>(S, 1) * sizeof(StructGrid)))) return rc;
+    if ((rc = reserve(ctx, ctx->sid, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rank_of, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->scan_sums, kScanBlocks * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
+    if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
+    if (has_id && (rc = reserve(ctx, ctx->sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
+    if ((rc = reserve(ctx, ctx->status, sizeof(BatchStatus)))) return rc;
+    if (!bt.out_atom_sasa && (rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
+
+    if (n_seg)
+        RS_HIP(ctx, hipMemcpyAsync(ctx->segments.p, ctx->h_segments, n_seg * sizeof(Segment),
+                                   hipMemcpyHostToDevice, st));
+
+    BatchView v{};
+    v.x = bt.x; v.y = bt.y; v.z = bt.z; v.radius = bt.radius; v.id = bt.id;
+    v.residue_offsets = bt.residue_offsets;
+    v.n_atoms = (uint32_t)N; v.n_structures = (uint32_t)S; v.n_residues = (uint32_t)R;
+    v.n_segments = (uint32_t)n_seg;
+    v.probe = pd.probe;
+    v.segments = (const Segment *)ctx->segments.p;
+    v.acc = (StructAcc *)ctx->acc.p;
+    v.grids = (StructGrid *)ctx->grids.p;
+    v.sid = (uint32_t *)ctx->sid.p;
+    v.cell_of = (uint32_t *)ctx->cell_of.p;
+    v.rank_of = (uint32_t *)ctx->rank_of.p;
+    v.cells = (uint32_t *)ctx->cells.p;
+    v.cell_capacity = ctx->cell_capacity;
+    v.scan_block_sums = (uint32_t *)ctx->scan_sums.p;
+    v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
+    v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
+    v.sorted_id = has_id ? (uint64_t *)ctx->sorted_id.p : nullptr;
+    v.status = (BatchStatus *)ctx->status.p;
+    v.atom_sasa = bt.out_atom_sasa ? bt.out_atom_sasa : (float *)ctx->atom_sasa.p;
+    v.residue_sasa = (R && bt.residue_offsets) ? bt.out_residue_sasa : nullptr;
+    v.neighbor_counts = bt.out_neighbor_counts;
+
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    launch_grid_build(v, st);
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+    launch_occlusion(v, lat, st);
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    launch_residue_sums(v, st);
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+    RS_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->status.p, sizeof(BatchStatus),
+                               hipMemcpyDeviceToHost, st));
+    RS_HIP(ctx, hipGetLastError());
+    return RSASA_OK;
+}
+
+int wait_pending(rsasa_context *ctx)
+{
+    Pending &pd = ctx->pending;
+    if (!pd.active) return RSASA_OK;
+    for (;;) {
+        hipError_t e = hipStreamSynchronize(pd.stream);
+        if (e != hipSuccess) {
+            pd.active = false;
+            return fail(ctx, RSASA_ERR_HIP, "hipStreamSynchronize", e);
+        }
+        const BatchStatus stt = *ctx->h_status;
+        if (stt.grid_too_large) {
+            pd.active = false;
+            return fail(ctx, RSASA_ERR_GRID_TOO_LARGE,
+                        "a structure's cell grid exceeds 2^31 cells (coordinates too sparse)");
+        }
+        if (stt.bad_input) {
+            pd.active = false;
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT,
+                        "probe_radius + max radius must be a positive finite number");
+        }
+        if (!stt.overflow) {
+            if (ctx->timing) {
+                float g = 0, o = 0, a = 0, t = 0;
+                (void)hipEventElapsedTime(&g, ctx->ev[0], ctx->ev[1]);
+                (void)hipEventElapsedTime(&o, ctx->ev[1], ctx->ev[2]);
+                (void)hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]);
+                (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]);
+                ctx->timings = rsasa_timings_t{g, o, a, t, stt.total_cells, pd.batch.n_atoms};
+                ctx->timings_valid = true;
+            }
+            pd.active = false;
+            return RSASA_OK;
+        }
+        // the cell array was too small for this batch: grow and run again
+        if (stt.total_cells >= 0xFFFFFFF0ull || pd.attempts >= 3) {
+            pd.active = false;
+            return fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "batch needs more than 2^32 grid cells; split it");
+        }
+        ctx->cell_capacity = stt.total_cells + stt.total_cells / 8 + 1024;
+        pd.attempts++;
+        int rc = enqueue_pending(ctx);
+        if (rc) {
+            pd.active = false;
+            return rc;
+        }
+    }
+}
+
+rsasa_context *g_default_ctx = nullptr;
+std::mutex g_default_mu;
+
+int resolve_ctx(rsasa_context *&ctx)
+{
+    if (ctx) return RSASA_OK;
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default_ctx) {
+        int rc = rsasa_context_create(0, &g_default_ctx);
+        if (rc) return rc;
+    }
+    ctx = g_default_ctx;
+    return RSASA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsasa_abi_version(void) { return RSASA_ABI_VERSION; }
+
+const char *rsasa_status_string(int status)
+{
+    switch (status) {
+    case RSASA_OK: return "ok";
+    case RSASA_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case RSASA_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+    case RSASA_ERR_HIP: return "HIP runtime error";
+    case RSASA_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case RSASA_ERR_GRID_TOO_LARGE: return "cell grid too large";
+    case RSASA_ERR_INTERNAL: return "internal error";
+    default: return "unknown status";
+    }
+}
+
+int rsasa_device_count(int *out_count)
+{
+    if (!out_count) return RSASA_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *out_count = n;
+    return RSASA_OK;
+}
+
+int rsasa_context_create(int device, rsasa_context_t **out_ctx)
+{
+    if (!out_ctx) return RSASA_ERR_INVALID_ARGUMENT;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return RSASA_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return RSASA_ERR_NO_DEVICE;
+    rsasa_context *ctx = new (std::nothrow) rsasa_context();
+    if (!ctx) return RSASA_ERR_OUT_OF_MEMORY;
+    ctx->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&ctx->h_status, sizeof(BatchStatus), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        rsasa_context_destroy(ctx);
+        return RSASA_ERR_HIP;
+    }
+    std::memset(ctx->h_status, 0, sizeof(BatchStatus));
+    *out_ctx = ctx;
+    return RSASA_OK;
+}
+
+int rsasa_context_destroy(rsasa_context_t *ctx)
+{
+    if (!ctx) return RSASA_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->sid, &ctx->cell_of,
+                            &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
+                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
+                            &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
+                            &ctx->in_res, &ctx->out_res, &ctx->out_k})
+        release(*b);
+    for (auto &kv : ctx->lattices)
+        if (kv.second.d) (void)hipFree(kv.second.d);
+    if (ctx->h_segments) (void)hipHostFree(ctx->h_segments);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    for (int i = 0; i < 4; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return RSASA_OK;
+}
+
+const char *rsasa_context_last_error(const rsasa_context_t *ctx)
+{
+    return ctx ? ctx->last_error.c_str() : "";
+}
+
+int rsasa_context_set_simd_width(rsasa_context_t *ctx, int w)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (w != 1 && w != 4 && w != 8 && w != 16)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "simd_width must be 1, 4, 8 or 16");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->simd_width = w;
+    return RSASA_OK;
+}
+
+int rsasa_context_enable_timing(rsasa_context_t *ctx, int enable)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->timing = enable != 0;
+    ctx->timings_valid = false;
+    return RSASA_OK;
+}
+
+int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (!out) return RSASA_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ctx->timings_valid)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "no timed batch has completed");
+    *out = ctx->timings;
+    return RSASA_OK;
+}
+
+int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
+                        float probe_radius, size_t n_points, void *hip_stream)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!batch) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "batch is NULL");
+    if (n_points == 0 || n_points > (1u << 24))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "n_points must be in [1, 2^24]");
+    if (!(probe_radius >= 0.0f) || !std::isfinite(probe_radius))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius must be finite and >= 0");
+    if (batch->n_atoms >= 0xFFFFFFF0ull || batch->n_structures >= 0xFFFFFFF0ull ||
+        batch->n_residues >= 0xFFFFFFF0ull)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "batch too large for 32-bit indices");
+    if (batch->n_atoms && (!batch->x || !batch->y || !batch->z || !batch->radius))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "coordinate / radius arrays are NULL");
+    if (batch->n_structures && !batch->structure_offsets_host)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets_host is NULL");
+    if (batch->n_structures) {
+        const uint32_t *o = batch->structure_offsets_host;
+        if (o[0] != 0 || o[batch->n_structures] != batch->n_atoms)
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must span [0, n_atoms]");
+        for (size_t s = 0; s < batch->n_structures; s++)
+            if (o[s] > o[s + 1])
+                return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must be non-decreasing");
+    } else if (batch->n_atoms) {
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "atoms without structures");
+    }
+    if (batch->n_residues && batch->residue_offsets && !batch->out_residue_sasa)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "out_residue_sasa is NULL");
+
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending.active) {
+        rc = wait_pending(ctx);
+        if (rc) return rc;
+    }
+    ctx->pending.batch = *batch;
+    ctx->pending.probe = probe_radius;
+    ctx->pending.n_points = n_points;
+    ctx->pending.stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    ctx->pending.attempts = 0;
+    rc = enqueue_pending(ctx);
+    ctx->pending.active = (rc == RSASA_OK);
+    return rc;
+}
+
+int rsasa_batch_wait(rsasa_context_t *ctx)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    return wait_pending(ctx);
+}
+
+int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float *y,
+                               const float *z, const float *radius, const uint64_t *id,
+                               const uint32_t *structure_offsets, size_t n_structures,
+                               float probe_radius, size_t n_points, float *out_atom_sasa,
+                               const uint32_t *residue_offsets, size_t n_residues,
+                               float *out_residue_sasa)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (n_structures && !structure_offsets)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets is NULL");
+    const size_t N = n_structures ? structure_offsets[n_structures] : 0;
+    const bool want_res = residue_offsets && n_residues;
+    if (N && (!x || !y || !z || !radius))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "coordinate / radius arrays are NULL");
+    if (want_res && !out_residue_sasa)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "out_residue_sasa is NULL");
+    if (N && !out_atom_sasa && !want_res)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "no output requested");
+    if (N == 0 && !want_res) return RSASA_OK;  // empty input -> empty output (tests/sanity.rs:149-157)
+    if (want_res) {
+        if (residue_offsets[n_residues] > N)
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets exceed n_atoms");
+        for (size_t k = 0; k < n_residues; k++)
+            if (residue_offsets[k] > residue_offsets[k + 1])
+                return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets must be non-decreasing");
+    }
+
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    {
+        RS_HIP(ctx, hipSetDevice(ctx->device));
+        if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+        const size_t n1 = std::max<size_t>(N, 1);
+        if ((rc = reserve(ctx, ctx->in_x, n1 * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->in_y, n1 * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->in_z, n1 * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->in_r, n1 * 4))) return rc;
+        if (id && (rc = reserve(ctx, ctx->in_id, n1 * 8))) return rc;
+        if ((rc = reserve(ctx, ctx->atom_sasa, n1 * 4))) return rc;
+        if (want_res) {
+            if ((rc = reserve(ctx, ctx->in_res, (n_residues + 1) * 4))) return rc;
+            if ((rc = reserve(ctx, ctx->out_res, n_residues * 4))) return rc;
+        }
+        hipStream_t st = ctx->stream;
+        if (N) {
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_x.p, x, N * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_y.p, y, N * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_z.p, z, N * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_r.p, radius, N * 4, hipMemcpyHostToDevice, st));
+            if (id) RS_HIP(ctx, hipMemcpyAsync(ctx->in_id.p, id, N * 8, hipMemcpyHostToDevice, st));
+        }
+        if (want_res)
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_res.p, residue_offsets, (n_residues + 1) * 4,
+                                       hipMemcpyHostToDevice, st));
+    }
+
+    rsasa_device_batch_t bt{};
+    bt.x = (const float *)ctx->in_x.p;
+    bt.y = (const float *)ctx->in_y.p;
+    bt.z = (const float *)ctx->in_z.p;
+    bt.radius = (const float *)ctx->in_r.p;
+    bt.id = id ? (const uint64_t *)ctx->in_id.p : nullptr;
+    bt.structure_offsets_host = structure_offsets;
+    bt.n_structures = n_structures;
+    bt.n_atoms = N;
+    bt.residue_offsets = want_res ? (const uint32_t *)ctx->in_res.p : nullptr;
+    bt.n_residues = want_res ? n_residues : 0;
+    bt.out_atom_sasa = (float *)ctx->atom_sasa.p;
+    bt.out_residue_sasa = want_res ? (float *)ctx->out_res.p : nullptr;
+    bt.out_neighbor_counts = nullptr;
+    if ((rc = rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr))) return rc;
+    if ((rc = rsasa_batch_wait(ctx))) return rc;
+
+    if (out_atom_sasa && N)
+        RS_HIP(ctx, hipMemcpy(out_atom_sasa, ctx->atom_sasa.p, N * 4, hipMemcpyDeviceToHost));
+    if (want_res)
+        RS_HIP(ctx, hipMemcpy(out_residue_sasa, ctx->out_res.p, n_residues * 4, hipMemcpyDeviceToHost));
+    return RSASA_OK;
+}
+
+int rsasa_calculate_sasa_soa(rsasa_context_t *ctx, const float *x, const float *y,
+                             const float *z, const float *radius, const uint64_t *id,
+                             size_t n_atoms, float probe_radius, size_t n_points,
+                             float *out_sasa)
+{
+    if (n_atoms >= 0xFFFFFFF0ull) return RSASA_ERR_INVALID_ARGUMENT;
+    if (n_atoms && !out_sasa) return RSASA_ERR_INVALID_ARGUMENT;
+    const uint32_t offsets[2] = {0u, (uint32_t)n_atoms};
+    return rsasa_calculate_sasa_batch(ctx, x, y, z, radius, id, offsets, 1, probe_radius, n_points,
+                                      out_sasa, nullptr, 0, nullptr);
+}
+
+int rsasa_calculate_sasa_internal(rsasa_context_t *ctx, const rsasa_atom_t *atoms,
+                                  size_t n_atoms, float probe_radius, size_t n_points,
+                                  ptrdiff_t threads, float *out_sasa)
+{
+    (void)threads;  // sequential-vs-rayon switch in the reference (src/lib.rs:278); no meaning here
+    if (n_atoms && (!atoms || !out_sasa)) return RSASA_ERR_INVALID_ARGUMENT;
+    std::vector<float> soa;
+    std::vector<uint64_t> ids;
+    try {
+        soa.resize(4 * n_atoms);
+        ids.resize(n_atoms);
+    } catch (const std::bad_alloc &) {
+        return RSASA_ERR_OUT_OF_MEMORY;
+    }
+    float *x = soa.data(), *y = x + n_atoms, *z = y + n_atoms, *r = z + n_atoms;
+    for (size_t i = 0; i < n_atoms; i++) {
+        x[i] = atoms[i].position[0];
+        y[i] = atoms[i].position[1];
+        z[i] = atoms[i].position[2];
+        r[i] = atoms[i].radius;
+        ids[i] = atoms[i].id;
+    }
+    return rsasa_calculate_sasa_soa(ctx, x, y, z, r, ids.data(), n_atoms, probe_radius, n_points,
+                                    out_sasa);
+}
+
+int rsasa_sphere_points(size_t n_points, float *out_x, float *out_y, float *out_z)
+{
+    if (!n_points || !out_x || !out_y || !out_z) return RSASA_ERR_INVALID_ARGUMENT;
+    generate_sphere_points(n_points, out_x, out_y, out_z);
+    return RSASA_OK;
+}
+
+}  // extern "C"

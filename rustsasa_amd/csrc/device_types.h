@@ -1,0 +1,90 @@
+// Shared host/device plain-data types of the SASA engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsasa {
+
+// Per-structure uniform cell grid, restating SpatialGrid::new
+// (reference src/structures/spatial_grid.rs:28-50).  64 bytes.
+struct StructGrid {
+    float min_x, min_y, min_z;     // bounding-box minimum minus cell_size (spatial_grid.rs:124-127)
+    float inv_cell;                // 1.0 / cell_size                      (spatial_grid.rs:36)
+    uint32_t dim_x, dim_y, dim_z;  // ceil(extent * inv_cell) + 1          (spatial_grid.rs:39-43)
+    uint32_t cell_base;            // first cell of this structure in the batch-wide cell array
+    float max_r;                   // fold(0.0, max) of the radii           (lib.rs:259-262)
+    float cell_size;               // probe + max_r                        (lib.rs:76)
+    uint32_t n_cells;
+    uint32_t pad[5];
+};
+static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
+
+// Order-preserving integer images of the running min/max, combined with
+// integer atomics by the bounds kernel.
+struct StructAcc {
+    int min_x, min_y, min_z;
+    int max_x, max_y, max_z;
+    int max_r;
+    int pad;
+};
+
+// A contiguous slice of one structure handled by one bounds workgroup.
+struct Segment {
+    uint32_t sid;
+    uint32_t begin;
+    uint32_t end;
+};
+
+// Deferred status of a batch, written on device, copied to pinned host memory.
+struct BatchStatus {
+    uint32_t overflow;        // total cells exceed the workspace capacity: re-run after growing
+    uint32_t grid_too_large;  // some structure needs more than 2^31 cells
+    uint32_t bad_input;       // probe + max_r <= 0 or non-finite bounds
+    uint32_t pad;
+    uint64_t total_cells;
+    uint64_t reserved;
+};
+
+struct Lattice {
+    const float *x, *y, *z;  // device SoA, padded with zeros to a multiple of 64 entries
+    uint32_t n_points;
+    uint32_t n_fused;        // points [0, n_fused) use the fused-FMA `<` rule (lib.rs:143-146);
+                             // the rest the scalar remainder rule (lib.rs:185-186,206-207)
+};
+
+// Everything a batch run needs on the device.  All pointers are device pointers.
+struct BatchView {
+    // inputs
+    const float *x, *y, *z, *radius;
+    const uint64_t *id;  // may be null
+    const uint32_t *residue_offsets;
+    uint32_t n_atoms, n_structures, n_residues, n_segments;
+    float probe;
+    // workspace
+    const Segment *segments;
+    StructAcc *acc;
+    StructGrid *grids;
+    uint32_t *sid;                // structure of atom i (same in input and cell-sorted order)
+    uint32_t *cell_of, *rank_of;  // global cell index / arrival rank inside the cell
+    uint32_t *cells;              // counts, then exclusive starts (cell_capacity + 1 entries)
+    uint64_t cell_capacity;
+    uint32_t *scan_block_sums;
+    float4 *sorted_xyzr;          // cell-sorted (x, y, z, radius)
+    uint32_t *sorted_orig;        // cell-sorted position -> input index
+    uint64_t *sorted_id;          // cell-sorted ids (only when id != null)
+    BatchStatus *status;
+    // outputs
+    float *atom_sasa;             // never null (workspace buffer when the caller passed none)
+    float *residue_sasa;          // may be null
+    uint32_t *neighbor_counts;    // may be null
+};
+
+// Launchers implemented in kernels.hip.  Each only enqueues on `stream`.
+void launch_grid_build(const BatchView &b, hipStream_t stream);
+void launch_occlusion(const BatchView &b, const Lattice &lat, hipStream_t stream);
+void launch_residue_sums(const BatchView &b, hipStream_t stream);
+
+constexpr uint32_t kSegmentAtoms = 4096;  // atoms per bounds workgroup
+constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
+
+}  // namespace rsasa

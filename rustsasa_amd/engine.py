@@ -1,0 +1,170 @@
+"""Python host wrapper over the C ABI: one `Context` per GPU.
+
+Mirrors the reference's free function `calculate_sasa_internal`
+(src/lib.rs:249-254) and its directory-mode batching (src/main.rs:375,439).
+All compute happens in the HIP library; this module only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import ATOM_DTYPE, DeviceBatch, RsasaError, Timings, check, ptr
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(_capi.load().rsasa_device_count(C.byref(n)))
+    return n.value
+
+
+def sphere_points(n_points: int):
+    """Golden-section-spiral lattice as uploaded to the GPU (src/lib.rs:43-66)."""
+    x = np.empty(n_points, np.float32)
+    y = np.empty(n_points, np.float32)
+    z = np.empty(n_points, np.float32)
+    check(_capi.load().rsasa_sphere_points(n_points, ptr(x), ptr(y), ptr(z)))
+    return x, y, z
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """One GPU, one HIP stream, one growable HBM workspace (rsasa_context_t)."""
+
+    def __init__(self, device: int = 0, simd_width: int = 8):
+        self._lib = _capi.load()
+        h = C.c_void_p()
+        check(self._lib.rsasa_context_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+        if simd_width != 8:
+            self.set_simd_width(simd_width)
+        self._keepalive = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rsasa_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, status):
+        check(status, self._h)
+
+    def set_simd_width(self, w: int):
+        self._check(self._lib.rsasa_context_set_simd_width(self._h, w))
+
+    # ---- single structure -------------------------------------------------
+    def calculate_sasa_internal(self, atoms: np.ndarray, probe_radius: float = 1.4,
+                                n_points: int = 100, threads: int = -1) -> np.ndarray:
+        """Drop-in for calculate_sasa_internal(&[Atom], probe, n_points, threads)."""
+        atoms = np.ascontiguousarray(atoms, dtype=ATOM_DTYPE)
+        out = np.zeros(atoms.shape[0], np.float32)
+        self._check(self._lib.rsasa_calculate_sasa_internal(
+            self._h, ptr(atoms), atoms.shape[0], probe_radius, n_points, threads, ptr(out)))
+        return out
+
+    def calculate_sasa_soa(self, x, y, z, radius, ids=None, probe_radius: float = 1.4,
+                           n_points: int = 100) -> np.ndarray:
+        x, y, z, radius = map(_f32, (x, y, z, radius))
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        out = np.zeros(x.shape[0], np.float32)
+        self._check(self._lib.rsasa_calculate_sasa_soa(
+            self._h, ptr(x), ptr(y), ptr(z), ptr(radius), ptr(ids), x.shape[0], probe_radius,
+            n_points, ptr(out)))
+        return out
+
+    # ---- many structures, host buffers -----------------------------------
+    def calculate_sasa_batch(self, x, y, z, radius, ids, structure_offsets,
+                             probe_radius: float = 1.4, n_points: int = 100,
+                             residue_offsets=None, want_atoms: bool = True):
+        x, y, z, radius = map(_f32, (x, y, z, radius))
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        so = np.ascontiguousarray(structure_offsets, dtype=np.uint32)
+        n_struct = so.shape[0] - 1
+        atom_out = np.zeros(x.shape[0], np.float32) if want_atoms else None
+        ro = res_out = None
+        n_res = 0
+        if residue_offsets is not None:
+            ro = np.ascontiguousarray(residue_offsets, dtype=np.uint32)
+            n_res = ro.shape[0] - 1
+            res_out = np.zeros(n_res, np.float32)
+        self._check(self._lib.rsasa_calculate_sasa_batch(
+            self._h, ptr(x), ptr(y), ptr(z), ptr(radius), ptr(ids), ptr(so), n_struct,
+            probe_radius, n_points, ptr(atom_out), ptr(ro), n_res, ptr(res_out)))
+        return atom_out, res_out
+
+    # ---- many structures, buffers already in HBM --------------------------
+    def enqueue_device(self, x, y, z, radius, ids, structure_offsets_host: np.ndarray,
+                       out_atom_sasa=None, residue_offsets=None, out_residue_sasa=None,
+                       out_neighbor_counts=None, probe_radius: float = 1.4, n_points: int = 100,
+                       stream: Optional[int] = None):
+        """Enqueue one batch whose arrays are torch CUDA(=HIP) tensors.
+
+        `stream` is a raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream);
+        None uses the context's own stream.  Call wait() before reading outputs.
+        """
+        so = np.ascontiguousarray(structure_offsets_host, dtype=np.uint32)
+
+        def dp(t):
+            return None if t is None else t.data_ptr()
+
+        b = DeviceBatch()
+        b.x, b.y, b.z, b.radius = dp(x), dp(y), dp(z), dp(radius)
+        b.id = dp(ids)
+        b.structure_offsets_host = so.ctypes.data
+        b.n_structures = so.shape[0] - 1
+        b.n_atoms = int(x.shape[0])
+        b.residue_offsets = dp(residue_offsets)
+        b.n_residues = 0 if residue_offsets is None else int(residue_offsets.shape[0]) - 1
+        b.out_atom_sasa = dp(out_atom_sasa)
+        b.out_residue_sasa = dp(out_residue_sasa)
+        b.out_neighbor_counts = dp(out_neighbor_counts)
+        # the library may re-run the batch from wait(): keep every buffer alive until then
+        self._keepalive = (so, x, y, z, radius, ids, residue_offsets, out_atom_sasa,
+                           out_residue_sasa, out_neighbor_counts)
+        self._check(self._lib.rsasa_batch_enqueue(self._h, C.byref(b), probe_radius, n_points,
+                                                  C.c_void_p(stream) if stream else None))
+
+    def wait(self):
+        self._check(self._lib.rsasa_batch_wait(self._h))
+        self._keepalive = None
+
+    # ---- measurement -------------------------------------------------------
+    def enable_timing(self, enable: bool = True):
+        self._check(self._lib.rsasa_context_enable_timing(self._h, 1 if enable else 0))
+
+    def timings(self) -> dict:
+        t = Timings()
+        self._check(self._lib.rsasa_context_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+
+def make_atoms(x, y, z, radius, ids) -> np.ndarray:
+    """Packs SoA columns into rsasa_atom_t records."""
+    a = np.zeros(len(x), ATOM_DTYPE)
+    a["position"][:, 0] = x
+    a["position"][:, 1] = y
+    a["position"][:, 2] = z
+    a["radius"] = radius
+    a["id"] = ids
+    return a
+
+
+__all__ = ["Context", "RsasaError", "device_count", "sphere_points", "make_atoms", "ATOM_DTYPE"]

@@ -21,6 +21,7 @@ DATA_FILES = [
     "tests/data/pdbs/bad_seqadv_1A06.pdb",
     "tests/data/freesasa_pdbs/1jcd.pdb",
     "tests/data/freesasa_pdbs/2drt.pdb",   # small clean multi-chain file with HETATM
+    "radii/protor.config",                 # ProtOr radii table (FreeSASA data file)
 ]
 
 
