@@ -91,6 +91,14 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch wheels bundle their own HIP runtime under the same SONAME
+        # (libamdhip64.so.7) as /opt/rocm's.  A process must hold exactly one of
+        # them, so when torch is installed it is imported first and this library
+        # binds to the runtime torch loaded; without torch it uses /opt/rocm's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)
