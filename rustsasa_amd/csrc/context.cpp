@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -88,6 +89,7 @@ struct rsasa_context {
 
     std::map<std::pair<size_t, int>, LatticeEntry> lattices;
     Pending pending;
+    OcclusionTuning tuning;
 };
 
 namespace {
@@ -258,7 +260,7 @@ int enqueue_pending(rsasa_context *ctx)
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     launch_grid_build(v, st);
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-    launch_occlusion(v, lat, st);
+    launch_occlusion(v, lat, ctx->tuning, st);
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     launch_residue_sums(v, st);
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
@@ -388,6 +390,8 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
         return RSASA_ERR_HIP;
     }
     std::memset(ctx->h_status, 0, sizeof(BatchStatus));
+    if (const char *v = std::getenv("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
+    if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
     *out_ctx = ctx;
     return RSASA_OK;
 }

@@ -79,9 +79,17 @@ struct BatchView {
     uint32_t *neighbor_counts;    // may be null
 };
 
-// Launchers implemented in kernels.hip.  Each only enqueues on `stream`.
+// Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
+// context; for A/B measurements -- every version computes identical results).
+struct OcclusionTuning {
+    int kernel_version = 1;       // 0 = straightforward all-pairs kernel, 1 = near/far two-phase kernel
+    uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
+};
+
+// Launchers implemented in kernels.hip / occlusion.hip.  Each only enqueues on `stream`.
 void launch_grid_build(const BatchView &b, hipStream_t stream);
-void launch_occlusion(const BatchView &b, const Lattice &lat, hipStream_t stream);
+void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
+                      hipStream_t stream);
 void launch_residue_sums(const BatchView &b, hipStream_t stream);
 
 constexpr uint32_t kSegmentAtoms = 4096;  // atoms per bounds workgroup

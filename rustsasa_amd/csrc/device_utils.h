@@ -1,0 +1,98 @@
+// Device-side helpers shared by the engine's kernels (gfx950 only).
+#pragma once
+#include "device_types.h"
+
+namespace rsasa {
+namespace {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------- helpers --
+
+__device__ __forceinline__ int f2ord(float f)
+{
+    int b = __float_as_int(f);
+    return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int o)
+{
+    return __int_as_float(o >= 0 ? o : o ^ 0x7FFFFFFF);
+}
+
+// Rust `f as u32`: saturating, NaN -> 0 (spatial_grid.rs:40-42,139-141).
+__device__ __forceinline__ uint32_t f2u_sat(float v)
+{
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
+
+// Orders this wave's LDS writes before its later LDS reads (same wave only).
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_bcast(T v, int src_lane)
+{
+    return __shfl(v, src_lane, kWave);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_incl_scan(T v)
+{
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        T t = __shfl_up(v, d, kWave);
+        if (l >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// Inclusive scan over a workgroup of kWave * NW threads; returns the inclusive
+// value and the workgroup total.  `smem` holds NW words.
+template <int NW, typename T>
+__device__ __forceinline__ T block_incl_scan(T v, T *smem, T &total)
+{
+    const uint32_t l = lane_id(), w = threadIdx.x / kWave;
+    T inc = wave_incl_scan(v);
+    __syncthreads();
+    if (l == kWave - 1) smem[w] = inc;
+    __syncthreads();
+    T off = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        T s = smem[i];
+        if ((uint32_t)i < w) off += s;
+        tot += s;
+    }
+    total = tot;
+    return inc + off;
+}
+
+__device__ __forceinline__ bool batch_aborted(const BatchStatus *st)
+{
+    return (st->overflow | st->grid_too_large) != 0;
+}
+
+// get_cell_index_static (spatial_grid.rs:133-143).  The clamps only matter for
+// non-finite input and keep the index inside the structure's cells.
+__device__ __forceinline__ void cell_coords(const StructGrid &g, float x, float y, float z,
+                                            uint32_t &cx, uint32_t &cy, uint32_t &cz)
+{
+    cx = min(f2u_sat((x - g.min_x) * g.inv_cell), g.dim_x - 1u);
+    cy = min(f2u_sat((y - g.min_y) * g.inv_cell), g.dim_y - 1u);
+    cz = min(f2u_sat((z - g.min_z) * g.inv_cell), g.dim_z - 1u);
+}
+
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+}  // namespace
+}  // namespace rsasa

@@ -11,82 +11,11 @@
 // with -ffp-contract=off; the only fused operations are the explicit
 // __builtin_fmaf calls that restate pulp's mul_add_f32s, reference
 // src/lib.rs:143-144).  Citations are relative to the reference tree.
-#include "device_types.h"
+#include "device_utils.h"
 
 namespace rsasa {
 
 namespace {
-
-constexpr int kWave = 64;
-
-// ---------------------------------------------------------------- helpers --
-
-__device__ __forceinline__ int f2ord(float f)
-{
-    int b = __float_as_int(f);
-    return b >= 0 ? b : b ^ 0x7FFFFFFF;
-}
-__device__ __forceinline__ float ord2f(int o)
-{
-    return __int_as_float(o >= 0 ? o : o ^ 0x7FFFFFFF);
-}
-
-// Rust `f as u32`: saturating, NaN -> 0 (spatial_grid.rs:40-42,139-141).
-__device__ __forceinline__ uint32_t f2u_sat(float v)
-{
-    if (!(v > 0.0f)) return 0u;
-    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
-    return (uint32_t)v;
-}
-
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
-
-// Orders this wave's LDS writes before its later LDS reads (same wave only).
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <typename T>
-__device__ __forceinline__ T wave_bcast(T v, int src_lane)
-{
-    return __shfl(v, src_lane, kWave);
-}
-
-template <typename T>
-__device__ __forceinline__ T wave_incl_scan(T v)
-{
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        T t = __shfl_up(v, d, kWave);
-        if (l >= (uint32_t)d) v += t;
-    }
-    return v;
-}
-
-// Inclusive scan over a workgroup of kWave * NW threads; returns the inclusive
-// value and the workgroup total.  `smem` holds NW words.
-template <int NW, typename T>
-__device__ __forceinline__ T block_incl_scan(T v, T *smem, T &total)
-{
-    const uint32_t l = lane_id(), w = threadIdx.x / kWave;
-    T inc = wave_incl_scan(v);
-    __syncthreads();
-    if (l == kWave - 1) smem[w] = inc;
-    __syncthreads();
-    T off = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        T s = smem[i];
-        if ((uint32_t)i < w) off += s;
-        tot += s;
-    }
-    total = tot;
-    return inc + off;
-}
 
 // ------------------------------------------------------ per-structure grid --
 
@@ -198,11 +127,6 @@ __global__ __launch_bounds__(1024) void k_finalize_grids(BatchView b)
     }
 }
 
-__device__ __forceinline__ bool batch_aborted(const BatchStatus *st)
-{
-    return (st->overflow | st->grid_too_large) != 0;
-}
-
 __global__ __launch_bounds__(256) void k_zero_cells(BatchView b)
 {
     if (batch_aborted(b.status)) return;
@@ -210,16 +134,6 @@ __global__ __launch_bounds__(256) void k_zero_cells(BatchView b)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (uint64_t)gridDim.x * blockDim.x)
         b.cells[i] = 0u;
-}
-
-// get_cell_index_static (spatial_grid.rs:133-143).  The clamps only matter for
-// non-finite input and keep the index inside the structure's cells.
-__device__ __forceinline__ void cell_coords(const StructGrid &g, float x, float y, float z,
-                                            uint32_t &cx, uint32_t &cy, uint32_t &cz)
-{
-    cx = min(f2u_sat((x - g.min_x) * g.inv_cell), g.dim_x - 1u);
-    cy = min(f2u_sat((y - g.min_y) * g.inv_cell), g.dim_y - 1u);
-    cz = min(f2u_sat((z - g.min_z) * g.inv_cell), g.dim_z - 1u);
 }
 
 // Count atoms per cell (spatial_grid.rs:53-62); the atomic's return value is
@@ -312,205 +226,6 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
     if (b.id) b.sorted_id[pos] = b.id[i];
 }
 
-// ---------------------------------------------------------------- occlusion --
-//
-// One wavefront per atom, atoms taken in cell-sorted order.
-//   1. lanes 0..24 fetch the 25 x-runs of cells that make up the 5x5x5 block
-//      around the atom's cell (search_extent = 2, spatial_grid.rs:47: the ratio
-//      max_search / cell_size is exactly 2 in f32);
-//   2. the runs are flattened and swept 64 atoms at a time: distance test with
-//      the reference's candidate rule d^2 <= (r_i + max_r + 2p)^2
-//      (spatial_grid.rs:307-308,335) and id rule (:314); each accepted lane
-//      computes its neighbour's (v, limit) (lib.rs:128-136) and appends it to
-//      the wave's LDS list;
-//   3. lanes become sphere points: every candidate is broadcast from LDS and
-//      tested against NCH chunks of 64 points (lib.rs:143-147), with the
-//      reference's remainder rule for the last n_points mod W points
-//      (lib.rs:185-186); surviving points are counted with ballot/popcount.
-
-constexpr int kCandCap = 192;    // LDS candidate slots per wave
-constexpr int kCandFlush = 128;  // flush once more than this many are queued
-
-struct OccArgs {
-    BatchView b;
-    Lattice lat;
-    uint32_t n_blocks;  // launched workgroups (for the XCD swizzle)
-};
-
-template <int NCH, bool HAS_ID>
-__global__ __launch_bounds__(256) void k_occlusion(OccArgs a)
-{
-    const BatchView &b = a.b;
-    if (batch_aborted(b.status)) return;
-    __shared__ float4 s_cand[4][kCandCap];
-    __shared__ uint32_t s_run_excl[4][32];
-    __shared__ uint32_t s_run_start[4][32];
-
-    const uint32_t lane = lane_id();
-    const uint32_t w = threadIdx.x / kWave;
-    // XCD-aware remap: workgroups are dealt round-robin over the 8 XCDs, so give
-    // each XCD a contiguous range of cell-sorted atoms (its L2 then holds only
-    // its own structures).
-    uint32_t bid = blockIdx.x;
-    {
-        const uint32_t per = a.n_blocks / 8u;
-        if (bid < per * 8u) bid = (bid % 8u) * per + bid / 8u;
-    }
-    const uint32_t p = bid * 4u + w;
-    if (p >= b.n_atoms) return;
-
-    const float probe = b.probe;
-    const float4 me = b.sorted_xyzr[p];
-    const StructGrid g = b.grids[b.sid[p]];
-    const float R = me.w + probe;                       // lib.rs:101
-    const float R2 = R * R;                             // lib.rs:102
-    const float twoR = 2.0f * R;                        // lib.rs:136
-    const float sr = me.w + g.max_r + 2.0f * probe;     // spatial_grid.rs:307
-    const float sr2 = sr * sr;                          // spatial_grid.rs:308
-    unsigned long long my_id = 0;
-    if (HAS_ID) my_id = b.sorted_id[p];
-
-    // -- 1. the 25 x-runs of the 5x5x5 cell block
-    uint32_t cx, cy, cz;
-    cell_coords(g, me.x, me.y, me.z, cx, cy, cz);
-    uint32_t run_start = 0, run_len = 0;
-    if (lane < 25) {
-        const int yy = (int)cy + (int)(lane % 5u) - 2;
-        const int zz = (int)cz + (int)(lane / 5u) - 2;
-        if (yy >= 0 && yy < (int)g.dim_y && zz >= 0 && zz < (int)g.dim_z) {
-            const uint32_t x0 = cx >= 2u ? cx - 2u : 0u;
-            const uint32_t x1 = min(cx + 2u, g.dim_x - 1u);
-            const uint32_t c0 = g.cell_base + x0 + (uint32_t)yy * g.dim_x +
-                                (uint32_t)zz * g.dim_x * g.dim_y;
-            run_start = b.cells[c0];
-            run_len = b.cells[c0 + (x1 - x0) + 1u] - run_start;
-        }
-    }
-    const uint32_t run_incl = wave_incl_scan(run_len);
-    const uint32_t total = wave_bcast(run_incl, 31);
-    if (lane < 32) {
-        s_run_excl[w][lane] = lane < 25 ? run_incl - run_len : 0xFFFFFFFFu;
-        s_run_start[w][lane] = run_start;
-    }
-    wave_lds_fence();
-
-    const uint32_t n_chunks = (a.lat.n_points + kWave - 1) / kWave;
-    float accessible = 0.0f;
-    uint32_t k_total = 0;
-
-    for (uint32_t ch0 = 0; ch0 < n_chunks; ch0 += NCH) {
-        // sphere points of this group of chunks; lanes past n_points start occluded
-        float sx[NCH], sy[NCH], sz[NCH];
-        unsigned long long occ[NCH], rem[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const uint32_t pi = (ch0 + c) * kWave + lane;  // lattice arrays are zero padded
-            const bool in_range = (ch0 + c) < n_chunks;
-            sx[c] = in_range ? a.lat.x[pi] : 0.0f;
-            sy[c] = in_range ? a.lat.y[pi] : 0.0f;
-            sz[c] = in_range ? a.lat.z[pi] : 0.0f;
-            occ[c] = __ballot(!(in_range && pi < a.lat.n_points));
-            rem[c] = __ballot(in_range && pi >= a.lat.n_fused && pi < a.lat.n_points);
-        }
-
-        uint32_t count = 0;
-        bool all_occluded = false;
-        for (uint32_t base = 0; base < total && !all_occluded; base += kWave) {
-            // -- 2. sweep 64 atoms of the block
-            const uint32_t f = base + lane;
-            bool accept = false;
-            float4 cand = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < total) {
-                uint32_t lo = 0;
-#pragma unroll
-                for (int step = 16; step > 0; step >>= 1)
-                    if (s_run_excl[w][lo + step] <= f) lo += step;
-                const uint32_t q = s_run_start[w][lo] + (f - s_run_excl[w][lo]);
-                const float4 o = b.sorted_xyzr[q];
-                const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;  // lib.rs:129-131
-                const float d2 = dx * dx + dy * dy + dz * dz;  // spatial_grid.rs:321 == lib.rs:132
-                accept = (q != p) && (d2 <= sr2);              // spatial_grid.rs:335
-                if (HAS_ID) {
-                    if (accept) accept = b.sorted_id[q] != my_id;  // spatial_grid.rs:314
-                }
-                const float tj = o.w + probe;                  // spatial_grid.rs:336
-                const float t = tj * tj;
-                cand = make_float4(dx, dy, dz, (t - d2 - R2) / twoR);  // lib.rs:136
-            }
-            const unsigned long long m = __ballot(accept);
-            if (accept) {
-                const uint32_t slot = count + __builtin_amdgcn_mbcnt_hi(
-                                                  (uint32_t)(m >> 32),
-                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                s_cand[w][slot] = cand;
-            }
-            count += (uint32_t)__popcll(m);
-            const bool last = base + kWave >= total;
-            if (count <= kCandFlush && !last) continue;
-
-            // -- 3. point tests over the queued candidates
-            wave_lds_fence();
-            if (ch0 == 0) k_total += count;
-            for (uint32_t k = 0; k < count; k++) {
-                const float4 cd = s_cand[w][k];
-                bool every = true;
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    // lib.rs:143-146: mul_add(sx, vx, mul_add(sy, vy, sz * vz)) < limit
-                    const float dot = __builtin_fmaf(sx[c], cd.x, __builtin_fmaf(sy[c], cd.y, sz[c] * cd.z));
-                    bool hit = dot < cd.w;
-                    if (rem[c] != 0ull) {
-                        // lib.rs:185-186,206-207: plain products, `<=`
-                        const float dotu = sx[c] * cd.x + sy[c] * cd.y + sz[c] * cd.z;
-                        const bool is_rem = (rem[c] >> lane) & 1ull;
-                        hit = is_rem ? (dotu <= cd.w) : hit;
-                    }
-                    occ[c] |= __ballot(hit);
-                    every = every && (occ[c] == ~0ull);
-                }
-                if (every) { all_occluded = true; break; }     // lib.rs:149-152
-            }
-            wave_lds_fence();
-            count = 0;
-        }
-        if (all_occluded && ch0 == 0) k_total = 0xFFFFFFFFu;  // swept only partly: recount below
-#pragma unroll
-        for (int c = 0; c < NCH; c++) accessible += (float)__popcll(~occ[c]);  // lib.rs:156-159
-    }
-
-    if (b.neighbor_counts && k_total == 0xFFFFFFFFu) {
-        // the early exit skipped part of the sweep; count the candidates without staging them
-        k_total = 0;
-        for (uint32_t base = 0; base < total; base += kWave) {
-            const uint32_t f = base + lane;
-            bool accept = false;
-            if (f < total) {
-                uint32_t lo = 0;
-#pragma unroll
-                for (int step = 16; step > 0; step >>= 1)
-                    if (s_run_excl[w][lo + step] <= f) lo += step;
-                const uint32_t q = s_run_start[w][lo] + (f - s_run_excl[w][lo]);
-                const float4 o = b.sorted_xyzr[q];
-                const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                accept = (q != p) && (d2 <= sr2);
-                if (HAS_ID) {
-                    if (accept) accept = b.sorted_id[q] != my_id;
-                }
-            }
-            k_total += (uint32_t)__popcll(__ballot(accept));
-        }
-    }
-
-    if (lane == 0) {
-        const uint32_t orig = b.sorted_orig[p];
-        const float surface_area = (4.0f * 3.14159274101257324219f) * R2;  // 4.0 * PI * r2, lib.rs:220
-        const float inv_n = 1.0f / (float)a.lat.n_points;      // lib.rs:221
-        b.atom_sasa[orig] = surface_area * accessible * inv_n; // lib.rs:222
-        if (b.neighbor_counts) b.neighbor_counts[orig] = k_total;
-    }
-}
-
 // ResidueLevel value: strictly sequential f32 sum of the residue's atoms in
 // input order (options.rs:209-216, utils.rs:14-22).  One thread per residue.
 __global__ __launch_bounds__(256) void k_residue_sums(BatchView b)
@@ -523,8 +238,6 @@ __global__ __launch_bounds__(256) void k_residue_sums(BatchView b)
         total += b.atom_sasa[i];
     b.residue_sasa[k] = total;
 }
-
-inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 }  // namespace
 
@@ -543,25 +256,6 @@ void launch_grid_build(const BatchView &b, hipStream_t stream)
     hipLaunchKernelGGL(k_scan_apply, dim3(kScanBlocks), dim3(256), 0, stream, b);
     if (b.n_atoms)
         hipLaunchKernelGGL(k_scatter, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);
-}
-
-template <int NCH>
-static void launch_occ(const OccArgs &a, hipStream_t stream)
-{
-    if (a.b.id)
-        hipLaunchKernelGGL((k_occlusion<NCH, true>), dim3(a.n_blocks), dim3(256), 0, stream, a);
-    else
-        hipLaunchKernelGGL((k_occlusion<NCH, false>), dim3(a.n_blocks), dim3(256), 0, stream, a);
-}
-
-void launch_occlusion(const BatchView &b, const Lattice &lat, hipStream_t stream)
-{
-    if (!b.n_atoms) return;
-    OccArgs a{b, lat, cdiv(b.n_atoms, 4)};
-    const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
-    if (n_chunks <= 2) launch_occ<2>(a, stream);
-    else if (n_chunks <= 4) launch_occ<4>(a, stream);
-    else launch_occ<16>(a, stream);
 }
 
 void launch_residue_sums(const BatchView &b, hipStream_t stream)

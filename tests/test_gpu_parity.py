@@ -305,3 +305,25 @@ def test_full_proteome_properties(ctx):
         want = po.calculate_sasa_internal(x, y, z, r, ids, PROBE, 100, 8)
         lo, hi = b.structure_offsets[s], b.structure_offsets[s + 1]
         assert np.array_equal(atom[lo:hi], want)
+
+
+@pytest.mark.parametrize("env", [{"RSASA_OCCLUSION_KERNEL": "0"},
+                                 {"RSASA_OCCLUSION_KERNEL": "1", "RSASA_ATOMS_PER_WAVE": "1"},
+                                 {"RSASA_OCCLUSION_KERNEL": "1", "RSASA_ATOMS_PER_WAVE": "7"}])
+def test_kernel_variants_agree(env, monkeypatch):
+    """Every occlusion kernel variant / wave schedule gives bit-identical results."""
+    import rustsasa_amd
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    b = bw.synthetic_proteome(60, seed=21)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                   8, threads=8)
+    with rustsasa_amd.Context(0) as c:
+        atom, _, k = _device_run(c, b)
+        atom960, _ = c.calculate_sasa_batch(b.x[:3000], b.y[:3000], b.z[:3000], b.radius[:3000],
+                                            b.ids[:3000], np.array([0, 3000], np.uint32), PROBE, 960)
+    assert np.array_equal(atom, want)
+    _, _, k_ref = po.calculate_sasa_internal(*b.structure(0), PROBE, 100, 8, return_details=True)
+    assert np.array_equal(k[:len(k_ref)], k_ref)
+    assert np.array_equal(atom960, po.calculate_sasa_internal(b.x[:3000], b.y[:3000], b.z[:3000],
+                                                              b.radius[:3000], b.ids[:3000], PROBE, 960, 8))
