@@ -82,7 +82,7 @@ struct BatchView {
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
-    int kernel_version = 1;       // 0 = straightforward all-pairs kernel, 1 = near/far two-phase kernel
+    int kernel_version = 2;       // 0 = all-pairs kernel, 1 = near/far two-phase, 2 = tiled two-phase
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
 };
 
