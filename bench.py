@@ -74,6 +74,31 @@ def cpu_baseline(batch, n_points, target_seconds):
                       f"structures, {t:.1f} s wall"}
 
 
+def aggregate(dist, dev, elapsed, n_structures, n_atoms):
+    """Whole-job numbers from per-rank ones: MAX of the elapsed times, SUM of the units.
+    `dist` is torch.distributed (RCCL on GPUs, gloo in the CPU tests) or None for one rank."""
+    units = torch.tensor([float(n_structures), float(n_atoms)], device=dev, dtype=torch.float64)
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(units, op=dist.ReduceOp.SUM)
+    return float(el.item()), float(units[0].item()), float(units[1].item())
+
+
+def make_workload(workload, structures, n_points, rank):
+    """Per-rank batch of independent structures (weak scaling: every rank gets its own)."""
+    if workload == "proteome":
+        n_points = n_points or N_POINTS
+        batch = bw.synthetic_proteome(structures, seed=bw.PROTEOME_SEED + rank)
+        name = (f"synthetic AlphaFold-E.coli-like proteome, {batch.n_structures} structures/GPU, "
+                f"{n_points} points, probe {PROBE}, ResidueLevel")
+    else:
+        n_points = n_points or 960
+        batch = bw.synthetic_uniform(1_000_000, seed=5 + rank)
+        name = f"synthetic 1M-atom structure, {n_points} points, probe {PROBE}, AtomLevel"
+    return batch, n_points, name
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -92,15 +117,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # ---- workload (independent structures; each rank gets its own batch) ----
-    if args.workload == "proteome":
-        n_points = args.n_points or N_POINTS
-        batch = bw.synthetic_proteome(args.structures, seed=bw.PROTEOME_SEED + rank)
-        name = (f"synthetic AlphaFold-E.coli-like proteome, {batch.n_structures} structures/GPU, "
-                f"{n_points} points, probe {PROBE}, ResidueLevel")
-    else:
-        n_points = args.n_points or 960
-        batch = bw.synthetic_uniform(1_000_000, seed=5 + rank)
-        name = f"synthetic 1M-atom structure, {n_points} points, probe {PROBE}, AtomLevel"
+    batch, n_points, name = make_workload(args.workload, args.structures, args.n_points, rank)
 
     def dv(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -145,14 +162,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    units = torch.tensor([float(batch.n_structures), float(batch.n_atoms)], device=dev,
-                         dtype=torch.float64)
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if dist:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(units, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    total_structures, total_atoms = float(units[0].item()), float(units[1].item())
+    elapsed, total_structures, total_atoms = aggregate(dist, dev, elapsed, batch.n_structures,
+                                                       batch.n_atoms)
 
     if rank == 0:
         occl = float(np.mean(occl_ms))

@@ -136,6 +136,14 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
                         float probe_radius, size_t n_points, void *hip_stream);
 int rsasa_batch_wait(rsasa_context_t *ctx);
 
+/* Strictly sequential f32 sums of contiguous segments of a host array, computed
+ * on the GPU: out[k] = ((values[o[k]] + values[o[k]+1]) + ...) over
+ * [offsets[k], offsets[k+1]).  This is the reference's simd_sum
+ * (src/utils.rs:14-22) as used by the level aggregations
+ * (src/options.rs:216,308,392,404). */
+int rsasa_segment_sums(rsasa_context_t *ctx, const float *values, size_t n_values,
+                       const uint32_t *offsets, size_t n_segments, float *out);
+
 /* ---- measurement ------------------------------------------------------- */
 
 /* When enabled, every rsasa_batch_enqueue brackets its kernels with HIP

@@ -1,0 +1,186 @@
+// rustsasa_amd.hpp -- C++ host API above the C ABI, mirroring RustSASA's level API
+// (reference src/options.rs): SASAOptions<Level>::process(), AtomLevel /
+// ResidueLevel / ChainLevel / ProteinLevel, the result structs of
+// src/structures/atomic.rs:26-70 and the error enum SASACalcError
+// (src/options.rs:466-494).
+//
+// Everything numeric happens on the GPU through include/rustsasa_amd.h
+// (rsasa_calculate_sasa_batch); this layer only selects atoms, looks up radii
+// and maps per-atom values to residues / chains exactly as the reference's
+// build_atoms_and_mapping / process_atoms do.  There is no CPU compute path.
+//
+// The reference parses files with the `pdbtbx` crate, whose source is not
+// available here; `Structure` is this library's own minimal PDB / mmCIF
+// atom-record model.  Differences that can matter are documented in DESIGN.md
+// ("Host API"): first MODEL only; a residue's first conformer is the first
+// (residue name, alt-loc) pair met in file order.
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "rustsasa_amd.h"
+
+namespace rustsasa {
+
+// ---- structure model (what the reference gets from pdbtbx::PDB) ------------
+struct AtomRecord {
+    bool hetero = false;      // HETATM record            (atom.hetero())
+    std::size_t serial = 0;   // atom serial number       (atom.serial_number())
+    std::string name;         // atom name, trimmed       (atom.name())
+    std::string element;      // upper-case element symbol, "" if unknown (atom.element())
+    double x = 0, y = 0, z = 0;
+    double occupancy = 1.0;
+    double b_factor = 0.0;
+};
+
+struct Conformer {
+    std::string name;     // residue name of this conformer
+    std::string alt_loc;  // "" when none
+    std::vector<AtomRecord> atoms;
+};
+
+struct Residue {
+    std::int64_t serial_number = 0;
+    std::string insertion_code;  // "" when none
+    std::vector<Conformer> conformers;
+    // Some(name) iff every conformer has the same name (pdbtbx Residue::name()).
+    bool name(std::string *out) const;
+};
+
+struct Chain {
+    std::string id;
+    std::vector<Residue> residues;
+};
+
+struct Structure {
+    std::vector<Chain> chains;
+    std::vector<std::string> warnings;
+    // Reads a PDB (ATOM/HETATM fixed columns) or mmCIF (_atom_site loop) file,
+    // chosen by extension (.cif / .mmcif => mmCIF).  Throws std::runtime_error.
+    static Structure open(const std::string &path);
+    static Structure from_pdb_text(const std::string &text);
+    static Structure from_mmcif_text(const std::string &text);
+    std::size_t atom_count() const;
+};
+
+// ---- radii -------------------------------------------------------------------
+using RadiiConfig = std::unordered_map<std::string, std::unordered_map<std::string, float>>;
+// FreeSASA-format config (reference src/utils/consts.rs:31-81).
+RadiiConfig parse_radii_config(const std::string &content);
+RadiiConfig load_radii_from_file(const std::string &path);  // throws std::runtime_error
+// Embedded ProtOr table (reference radii/protor.config via PROTOR_RADII).
+bool get_protor_radius(const std::string &residue, const std::string &atom, float *out);
+// van-der-Waals radius of an element symbol (fallback of build_atom!, options.rs:89-93).
+bool vdw_radius(const std::string &element, float *out);
+
+// ---- results (reference src/structures/atomic.rs:26-70) -----------------------
+struct ResidueResult {
+    std::int64_t serial_number;
+    std::string insertion_code;
+    float value;
+    std::string name;
+    bool is_polar;
+    std::string chain_id;
+};
+struct ChainResult {
+    std::string name;
+    float value;
+};
+struct ProteinResult {
+    float global_total, polar_total, non_polar_total;
+};
+
+// ---- errors (reference src/options.rs:466-494) ---------------------------------
+enum class SASACalcError {
+    Ok = 0,
+    ElementMissing,
+    VanDerWaalsMissing,
+    RadiusMissing,
+    AtomMapToLevelElementFailed,
+    FailedToGetResidueName,
+    RadiiFileLoad,
+    Engine,  // not in the reference: the GPU engine reported an error (see message)
+};
+
+template <typename T>
+struct Result {
+    SASACalcError error = SASACalcError::Ok;
+    std::string message;  // Display text of the reference's error
+    T value{};
+    bool ok() const { return error == SASACalcError::Ok; }
+};
+
+// ---- levels ---------------------------------------------------------------------
+struct AtomLevel { using Output = std::vector<float>; };
+struct ResidueLevel { using Output = std::vector<ResidueResult>; };
+struct ChainLevel { using Output = std::vector<ChainResult>; };
+struct ProteinLevel { using Output = ProteinResult; };
+
+// Selected atoms in hot-path form plus the parent -> atom-index map
+// (reference AtomsMappingResult, options.rs:78).
+struct AtomsAndMapping {
+    std::vector<rsasa_atom_t> atoms;
+    std::map<std::int64_t, std::vector<std::size_t>> parent_to_atoms;
+};
+
+struct OptionValues {
+    float probe_radius = 1.4f;        // options.rs:500
+    std::size_t n_points = 100;       // options.rs:501
+    std::ptrdiff_t threads = -1;      // options.rs:502 (no meaning on the GPU; kept for the signature)
+    bool include_hydrogens = false;   // options.rs:503
+    std::shared_ptr<const RadiiConfig> radii_config;  // options.rs:504
+    bool allow_vdw_fallback = false;  // options.rs:505
+    bool include_hetatms = false;     // options.rs:506
+    bool read_radii_from_occupancy = false;  // options.rs:507
+    rsasa_context_t *context = nullptr;      // GPU context; nullptr = the library's default (device 0)
+};
+
+namespace detail {
+template <typename Level>
+struct Processor;  // build_atoms_and_mapping / process_atoms per level (options.rs:139-464)
+Result<std::vector<float>> run_hot_path(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms);
+}  // namespace detail
+
+template <typename Level>
+class SASAOptions {
+public:
+    SASAOptions() = default;                                      // options.rs:498-510
+    SASAOptions &with_probe_radius(float r) { o_.probe_radius = r; return *this; }
+    SASAOptions &with_include_hetatms(bool v) { o_.include_hetatms = v; return *this; }
+    SASAOptions &with_n_points(std::size_t n) { o_.n_points = n; return *this; }
+    SASAOptions &with_read_radii_from_occupancy(bool v) { o_.read_radii_from_occupancy = v; return *this; }
+    SASAOptions &with_threads(std::ptrdiff_t t) { o_.threads = t; return *this; }
+    SASAOptions &with_include_hydrogens(bool v) { o_.include_hydrogens = v; return *this; }
+    SASAOptions &with_radii_file(const std::string &path)         // throws std::runtime_error
+    {
+        o_.radii_config = std::make_shared<const RadiiConfig>(load_radii_from_file(path));
+        return *this;
+    }
+    SASAOptions &with_allow_vdw_fallback(bool v) { o_.allow_vdw_fallback = v; return *this; }
+    SASAOptions &with_context(rsasa_context_t *ctx) { o_.context = ctx; return *this; }
+    const OptionValues &values() const { return o_; }
+
+    // options.rs:606-618
+    Result<typename Level::Output> process(const Structure &pdb) const;
+
+private:
+    OptionValues o_;
+};
+
+extern template class SASAOptions<AtomLevel>;
+extern template class SASAOptions<ResidueLevel>;
+extern template class SASAOptions<ChainLevel>;
+extern template class SASAOptions<ProteinLevel>;
+
+// helpers shared with the reference's utils.rs
+std::int64_t serialize_chain_id(const std::string &s);                  // utils.rs:24-33
+std::uint64_t fnv_hash_altloc_serial(const std::string &alt, std::size_t serial);  // utils.rs:83-87
+bool is_polar_residue(const std::string &name);                        // consts.rs:7-16
+
+}  // namespace rustsasa

@@ -629,6 +629,43 @@ int rsasa_calculate_sasa_internal(rsasa_context_t *ctx, const rsasa_atom_t *atom
                                     out_sasa);
 }
 
+int rsasa_segment_sums(rsasa_context_t *ctx, const float *values, size_t n_values,
+                       const uint32_t *offsets, size_t n_segments, float *out)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (n_segments == 0) return RSASA_OK;
+    if (!offsets || !out || (n_values && !values))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n_values >= 0xFFFFFFF0ull || n_segments >= 0xFFFFFFF0ull || offsets[n_segments] > n_values)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "offsets exceed n_values");
+    for (size_t k = 0; k < n_segments; k++)
+        if (offsets[k] > offsets[k + 1])
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+    if ((rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(n_values, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->in_res, (n_segments + 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->out_res, n_segments * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->status, sizeof(BatchStatus)))) return rc;
+    hipStream_t st = ctx->stream;
+    RS_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, sizeof(BatchStatus), st));
+    if (n_values)
+        RS_HIP(ctx, hipMemcpyAsync(ctx->atom_sasa.p, values, n_values * 4, hipMemcpyHostToDevice, st));
+    RS_HIP(ctx, hipMemcpyAsync(ctx->in_res.p, offsets, (n_segments + 1) * 4, hipMemcpyHostToDevice, st));
+    BatchView v{};
+    v.residue_offsets = (const uint32_t *)ctx->in_res.p;
+    v.n_residues = (uint32_t)n_segments;
+    v.status = (BatchStatus *)ctx->status.p;
+    v.atom_sasa = (float *)ctx->atom_sasa.p;
+    v.residue_sasa = (float *)ctx->out_res.p;
+    launch_residue_sums(v, st);
+    RS_HIP(ctx, hipMemcpyAsync(out, ctx->out_res.p, n_segments * 4, hipMemcpyDeviceToHost, st));
+    RS_HIP(ctx, hipStreamSynchronize(st));
+    return RSASA_OK;
+}
+
 int rsasa_sphere_points(size_t n_points, float *out_x, float *out_y, float *out_z)
 {
     if (!n_points || !out_x || !out_y || !out_z) return RSASA_ERR_INVALID_ARGUMENT;

@@ -1,0 +1,645 @@
+// Host API above the C ABI (include/rustsasa_amd.hpp): minimal PDB / mmCIF
+// reader, radii lookup, and the four level processors of the reference's
+// src/options.rs.  No SASA arithmetic happens here: per-atom values and the
+// sequential f32 segment sums come from the GPU (rsasa_calculate_sasa_batch).
+#include "../../../include/rustsasa_amd.hpp"
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace rustsasa {
+
+// ------------------------------------------------------------------ utils --
+
+static std::string trim(const std::string &s)
+{
+    size_t b = 0, e = s.size();
+    while (b < e && std::isspace((unsigned char)s[b])) b++;
+    while (e > b && std::isspace((unsigned char)s[e - 1])) e--;
+    return s.substr(b, e - b);
+}
+
+static std::string upper(std::string s)
+{
+    for (auto &c : s) c = (char)std::toupper((unsigned char)c);
+    return s;
+}
+
+// utils.rs:24-33
+std::int64_t serialize_chain_id(const std::string &s)
+{
+    std::int64_t result = 0;
+    for (unsigned char c : s)
+        if (std::isalpha(c)) result = result * 10 + ((std::int64_t)std::toupper(c) - 64);
+    return result;
+}
+
+// utils.rs:83-87 applied to (&str, usize): FNV-1a over the str bytes, the 0xff
+// str terminator of Rust's Hash impl, then the little-endian usize.
+std::uint64_t fnv_hash_altloc_serial(const std::string &alt, std::size_t serial)
+{
+    std::uint64_t h = 0xcbf29ce484222325ull;
+    auto feed = [&h](unsigned char b) { h ^= b; h *= 0x100000001b3ull; };
+    for (unsigned char c : alt) feed(c);
+    feed(0xff);
+    std::uint64_t v = (std::uint64_t)serial;
+    for (int i = 0; i < 8; i++) feed((unsigned char)(v >> (8 * i)));
+    return h;
+}
+
+// consts.rs:7-16
+bool is_polar_residue(const std::string &name)
+{
+    static const char *polar[] = {"SER", "THR", "CYS", "ASN", "GLN", "TYR"};
+    for (const char *p : polar)
+        if (name == p) return true;
+    return false;
+}
+
+// ------------------------------------------------------------------ radii --
+
+struct ProtorEntry { const char *residue, *atom; float radius; };
+static const ProtorEntry kProtor[] = {
+#include "protor_table.inc"
+};
+
+static const RadiiConfig &protor_map()
+{
+    static const RadiiConfig m = [] {
+        RadiiConfig t;
+        for (const auto &e : kProtor) t[e.residue][e.atom] = e.radius;
+        return t;
+    }();
+    return m;
+}
+
+bool get_protor_radius(const std::string &residue, const std::string &atom, float *out)
+{
+    const auto &m = protor_map();
+    auto r = m.find(residue);
+    if (r == m.end()) return false;
+    auto a = r->second.find(atom);
+    if (a == r->second.end()) return false;
+    *out = a->second;
+    return true;
+}
+
+// consts.rs:31-81
+RadiiConfig parse_radii_config(const std::string &content)
+{
+    std::unordered_map<std::string, float> types;
+    RadiiConfig atoms;
+    bool in_types = false, in_atoms = false;
+    std::istringstream is(content);
+    std::string raw;
+    while (std::getline(is, raw)) {
+        std::string line = trim(raw);
+        if (line.empty() || line[0] == '#' || line.rfind("name:", 0) == 0) continue;
+        if (line == "types:") { in_types = true; in_atoms = false; continue; }
+        if (line == "atoms:") { in_types = false; in_atoms = true; continue; }
+        std::istringstream ls(line);
+        std::vector<std::string> p;
+        for (std::string t; ls >> t;) p.push_back(t);
+        if (in_types && p.size() >= 2) {
+            char *end = nullptr;
+            float v = std::strtof(p[1].c_str(), &end);
+            if (end && *end == '\0') types[p[0]] = v;
+        } else if (in_atoms && p.size() >= 3) {
+            auto t = types.find(p[2]);
+            if (t != types.end()) atoms[p[0]][p[1]] = t->second;
+        }
+    }
+    return atoms;
+}
+
+RadiiConfig load_radii_from_file(const std::string &path)
+{
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("Failed to load radii file: " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return parse_radii_config(ss.str());
+}
+
+// Element van-der-Waals radii (Alvarez 2013, the table pdbtbx's
+// Element::atomic_radius().van_der_waals is built from).  The reference's own
+// tests pin N, C, O, S (tests/units.rs:18-43); the rest is unpinned here.
+bool vdw_radius(const std::string &element, float *out)
+{
+    static const std::pair<const char *, float> t[] = {
+        {"H", 1.20f},  {"HE", 1.43f}, {"LI", 2.12f}, {"BE", 1.98f}, {"B", 1.91f},  {"C", 1.77f},
+        {"N", 1.66f},  {"O", 1.50f},  {"F", 1.46f},  {"NE", 1.58f}, {"NA", 2.50f}, {"MG", 2.51f},
+        {"AL", 2.25f}, {"SI", 2.19f}, {"P", 1.90f},  {"S", 1.89f},  {"CL", 1.82f}, {"AR", 1.83f},
+        {"K", 2.73f},  {"CA", 2.62f}, {"SC", 2.58f}, {"TI", 2.46f}, {"V", 2.42f},  {"CR", 2.45f},
+        {"MN", 2.45f}, {"FE", 2.44f}, {"CO", 2.40f}, {"NI", 2.40f}, {"CU", 2.38f}, {"ZN", 2.39f},
+        {"GA", 2.32f}, {"GE", 2.29f}, {"AS", 1.88f}, {"SE", 1.82f}, {"BR", 1.86f}, {"KR", 2.25f},
+        {"RB", 3.21f}, {"SR", 2.84f}, {"MO", 2.45f}, {"CD", 2.49f}, {"I", 2.04f},  {"XE", 2.06f},
+        {"CS", 3.48f}, {"BA", 3.03f}, {"W", 2.57f},  {"PT", 2.29f}, {"AU", 2.32f}, {"HG", 2.45f},
+        {"PB", 2.60f}, {"U", 2.71f},  {"D", 1.20f}};
+    for (const auto &e : t)
+        if (element == e.first) { *out = e.second; return true; }
+    return false;
+}
+
+// ---------------------------------------------------------------- Structure --
+
+bool Residue::name(std::string *out) const
+{
+    if (conformers.empty()) return false;
+    for (const auto &c : conformers)
+        if (c.name != conformers.front().name) return false;
+    *out = conformers.front().name;
+    return true;
+}
+
+std::size_t Structure::atom_count() const
+{
+    std::size_t n = 0;
+    for (const auto &c : chains)
+        for (const auto &r : c.residues)
+            for (const auto &f : r.conformers) n += f.atoms.size();
+    return n;
+}
+
+namespace {
+
+struct FlatAtom {
+    AtomRecord rec;
+    std::string alt, res_name, chain;
+    std::int64_t res_seq = 0;
+    std::string icode;
+};
+
+// pdbtbx-style insertion: chains by id, residues by (number, insertion code),
+// conformers by (name, alt-loc); existing entries are found searching from the back.
+void add_atom(Structure &s, const FlatAtom &a)
+{
+    Chain *chain = nullptr;
+    for (auto it = s.chains.rbegin(); it != s.chains.rend(); ++it)
+        if (it->id == a.chain) { chain = &*it; break; }
+    if (!chain) {
+        s.chains.push_back(Chain{a.chain, {}});
+        chain = &s.chains.back();
+    }
+    Residue *res = nullptr;
+    for (auto it = chain->residues.rbegin(); it != chain->residues.rend(); ++it)
+        if (it->serial_number == a.res_seq && it->insertion_code == a.icode) { res = &*it; break; }
+    if (!res) {
+        chain->residues.push_back(Residue{a.res_seq, a.icode, {}});
+        res = &chain->residues.back();
+    }
+    Conformer *conf = nullptr;
+    for (auto &c : res->conformers)
+        if (c.name == a.res_name && c.alt_loc == a.alt) { conf = &c; break; }
+    if (!conf) {
+        res->conformers.push_back(Conformer{a.res_name, a.alt, {}});
+        conf = &res->conformers.back();
+    }
+    conf->atoms.push_back(a.rec);
+}
+
+std::string element_from_name(const std::string &name)
+{
+    for (unsigned char c : name)
+        if (std::isalpha(c)) return std::string(1, (char)std::toupper(c));
+    return "";
+}
+
+std::string field(const std::string &line, size_t from, size_t to)  // 1-based inclusive columns
+{
+    if (line.size() < from) return "";
+    return trim(line.substr(from - 1, std::min(to, line.size()) - from + 1));
+}
+
+// mmCIF tokenizer for one line: whitespace separated, '...' and "..." quoting.
+void tokenize(const std::string &line, std::vector<std::string> &out)
+{
+    out.clear();
+    size_t i = 0, n = line.size();
+    while (i < n) {
+        while (i < n && std::isspace((unsigned char)line[i])) i++;
+        if (i >= n) break;
+        if (line[i] == '\'' || line[i] == '"') {
+            const char q = line[i++];
+            size_t j = i;
+            while (j < n && !(line[j] == q && (j + 1 == n || std::isspace((unsigned char)line[j + 1])))) j++;
+            out.push_back(line.substr(i, j - i));
+            i = j + 1;
+        } else {
+            size_t j = i;
+            while (j < n && !std::isspace((unsigned char)line[j])) j++;
+            out.push_back(line.substr(i, j - i));
+            i = j;
+        }
+    }
+}
+
+}  // namespace
+
+Structure Structure::from_pdb_text(const std::string &text)
+{
+    Structure s;
+    std::istringstream is(text);
+    std::string line;
+    bool in_first_model = true, seen_model = false;
+    std::size_t counter = 0;
+    while (std::getline(is, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.rfind("MODEL", 0) == 0) {
+            if (seen_model) in_first_model = false;
+            seen_model = true;
+            continue;
+        }
+        if (line.rfind("ENDMDL", 0) == 0) { in_first_model = false; continue; }
+        const bool is_atom = line.rfind("ATOM  ", 0) == 0, is_het = line.rfind("HETATM", 0) == 0;
+        if (!(is_atom || is_het) || !in_first_model) continue;
+        if (line.size() < 54) { s.warnings.push_back("short ATOM record skipped"); continue; }
+        FlatAtom a;
+        counter++;
+        a.rec.hetero = is_het;
+        const std::string serial = field(line, 7, 11);
+        char *end = nullptr;
+        long sv = std::strtol(serial.c_str(), &end, 10);
+        a.rec.serial = (end && *end == '\0' && !serial.empty()) ? (std::size_t)sv : counter;
+        a.rec.name = field(line, 13, 16);
+        a.alt = field(line, 17, 17);
+        a.res_name = field(line, 18, 20);
+        a.chain = field(line, 22, 22);
+        a.res_seq = std::strtol(field(line, 23, 26).c_str(), nullptr, 10);
+        a.icode = field(line, 27, 27);
+        a.rec.x = std::strtod(field(line, 31, 38).c_str(), nullptr);
+        a.rec.y = std::strtod(field(line, 39, 46).c_str(), nullptr);
+        a.rec.z = std::strtod(field(line, 47, 54).c_str(), nullptr);
+        const std::string occ = field(line, 55, 60), bf = field(line, 61, 66);
+        a.rec.occupancy = occ.empty() ? 1.0 : std::strtod(occ.c_str(), nullptr);
+        a.rec.b_factor = bf.empty() ? 0.0 : std::strtod(bf.c_str(), nullptr);
+        a.rec.element = upper(field(line, 77, 78));
+        if (a.rec.element.empty()) a.rec.element = element_from_name(a.rec.name);
+        add_atom(s, a);
+    }
+    return s;
+}
+
+Structure Structure::from_mmcif_text(const std::string &text)
+{
+    Structure s;
+    std::istringstream is(text);
+    std::string line;
+    std::vector<std::string> cols, tok;
+    bool in_loop = false, in_atom_site = false;
+    std::string first_model;
+    auto col = [&](const char *name) -> int {
+        for (size_t i = 0; i < cols.size(); i++)
+            if (cols[i] == name) return (int)i;
+        return -1;
+    };
+    int c_group = -1, c_id = -1, c_sym = -1, c_atom = -1, c_alt = -1, c_comp = -1, c_lasym = -1,
+        c_aasym = -1, c_lseq = -1, c_aseq = -1, c_ins = -1, c_x = -1, c_y = -1, c_z = -1, c_occ = -1,
+        c_b = -1, c_model = -1;
+    bool resolved = false;
+    auto val = [&](int c) -> std::string {
+        if (c < 0 || c >= (int)tok.size()) return "";
+        return (tok[c] == "." || tok[c] == "?") ? "" : tok[c];
+    };
+    while (std::getline(is, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        const std::string t = trim(line);
+        if (t.empty()) continue;
+        if (t == "loop_") { in_loop = true; in_atom_site = false; cols.clear(); resolved = false; continue; }
+        if (t[0] == '#') { in_loop = false; in_atom_site = false; continue; }
+        if (in_loop && t[0] == '_') {
+            if (t.rfind("_atom_site.", 0) == 0) {
+                in_atom_site = true;
+                std::string name = t.substr(11);
+                name = trim(name.substr(0, name.find_first_of(" \t")));
+                cols.push_back(name);
+            } else {
+                in_atom_site = false;
+            }
+            continue;
+        }
+        if (!(in_loop && in_atom_site)) continue;
+        if (t[0] == '_' ) { in_loop = false; continue; }
+        if (!resolved) {
+            c_group = col("group_PDB"); c_id = col("id"); c_sym = col("type_symbol");
+            c_atom = col("label_atom_id"); c_alt = col("label_alt_id"); c_comp = col("label_comp_id");
+            c_lasym = col("label_asym_id"); c_aasym = col("auth_asym_id"); c_lseq = col("label_seq_id");
+            c_aseq = col("auth_seq_id"); c_ins = col("pdbx_PDB_ins_code"); c_x = col("Cartn_x");
+            c_y = col("Cartn_y"); c_z = col("Cartn_z"); c_occ = col("occupancy");
+            c_b = col("B_iso_or_equiv"); c_model = col("pdbx_PDB_model_num");
+            resolved = true;
+            if (c_x < 0 || c_y < 0 || c_z < 0 || c_atom < 0 || c_comp < 0)
+                throw std::runtime_error("mmCIF _atom_site loop lacks required columns");
+        }
+        tokenize(t, tok);
+        if (tok.size() < cols.size()) { s.warnings.push_back("short _atom_site row skipped"); continue; }
+        const std::string model = val(c_model);
+        if (first_model.empty()) first_model = model.empty() ? "1" : model;
+        if (!model.empty() && model != first_model) continue;
+        FlatAtom a;
+        a.rec.hetero = val(c_group) == "HETATM";
+        a.rec.serial = (std::size_t)std::strtoul(val(c_id).c_str(), nullptr, 10);
+        a.rec.name = val(c_atom);
+        a.alt = val(c_alt);
+        a.res_name = val(c_comp);
+        a.chain = c_aasym >= 0 && !val(c_aasym).empty() ? val(c_aasym) : val(c_lasym);
+        const std::string seq = c_aseq >= 0 && !val(c_aseq).empty() ? val(c_aseq) : val(c_lseq);
+        a.res_seq = std::strtol(seq.c_str(), nullptr, 10);
+        a.icode = val(c_ins);
+        a.rec.x = std::strtod(val(c_x).c_str(), nullptr);
+        a.rec.y = std::strtod(val(c_y).c_str(), nullptr);
+        a.rec.z = std::strtod(val(c_z).c_str(), nullptr);
+        a.rec.occupancy = val(c_occ).empty() ? 1.0 : std::strtod(val(c_occ).c_str(), nullptr);
+        a.rec.b_factor = val(c_b).empty() ? 0.0 : std::strtod(val(c_b).c_str(), nullptr);
+        a.rec.element = upper(val(c_sym));
+        if (a.rec.element.empty()) a.rec.element = element_from_name(a.rec.name);
+        add_atom(s, a);
+    }
+    return s;
+}
+
+Structure Structure::open(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string ext = upper(path.substr(path.find_last_of('.') == std::string::npos ? path.size() : path.find_last_of('.')));
+    if (ext == ".CIF" || ext == ".MMCIF") return from_mmcif_text(ss.str());
+    return from_pdb_text(ss.str());
+}
+
+// ------------------------------------------------------------------ levels --
+
+namespace detail {
+
+namespace {
+
+struct BuildError {
+    SASACalcError error = SASACalcError::Ok;
+    std::string message;
+};
+
+// build_atom! (options.rs:81-116)
+bool build_atom(const OptionValues &o, const AtomRecord &atom, const std::string &residue_name,
+                std::uint64_t id, std::vector<rsasa_atom_t> &atoms, BuildError &err)
+{
+    float radius = 0.f;
+    if (o.read_radii_from_occupancy) {
+        radius = (float)atom.occupancy;
+    } else {
+        bool found = false;
+        if (o.radii_config) {  // utils.rs:45-53
+            auto r = o.radii_config->find(residue_name);
+            if (r != o.radii_config->end()) {
+                auto a = r->second.find(atom.name);
+                if (a != r->second.end()) { radius = a->second; found = true; }
+            }
+        }
+        if (!found) found = get_protor_radius(residue_name, atom.name, &radius);
+        if (!found) {
+            if (o.allow_vdw_fallback) {
+                if (!vdw_radius(atom.element, &radius)) {
+                    err = {SASACalcError::VanDerWaalsMissing, "Van der Waals radius missing for element"};
+                    return false;
+                }
+            } else {
+                err = {SASACalcError::RadiusMissing,
+                       "Radius not found for residue '" + residue_name + "' atom '" + atom.name +
+                           "' of type '" + atom.element +
+                           "'. This error can can be ignored, if you are using the CLI pass "
+                           "--allow-vdw-fallback or use with_allow_vdw_fallback if you are using the API."};
+                return false;
+            }
+        }
+    }
+    rsasa_atom_t a;
+    a.position[0] = (float)atom.x;  // options.rs:106-110: f64 -> f32
+    a.position[1] = (float)atom.y;
+    a.position[2] = (float)atom.z;
+    a.radius = radius;
+    a.id = id;
+    atoms.push_back(a);
+    return true;
+}
+
+// The atom loop shared by all four build_atoms_and_mapping bodies: chains ->
+// residues -> FIRST conformer -> atoms, hydrogen / HETATM filters.  `per_residue`
+// is told each residue's range of kept atoms.
+template <typename F>
+bool select_atoms(const Structure &pdb, const OptionValues &o, bool id_uses_altloc,
+                  std::vector<rsasa_atom_t> &atoms, BuildError &err, F per_residue)
+{
+    for (size_t ci = 0; ci < pdb.chains.size(); ci++) {
+        const Chain &chain = pdb.chains[ci];
+        for (size_t ri = 0; ri < chain.residues.size(); ri++) {
+            const Residue &res = chain.residues[ri];
+            std::string residue_name;
+            if (!res.name(&residue_name)) {  // options.rs:161,248
+                err = {SASACalcError::FailedToGetResidueName, "Failed to get residue name"};
+                return false;
+            }
+            const size_t begin = atoms.size();
+            if (!res.conformers.empty()) {
+                const Conformer &conf = res.conformers.front();  // conformers().next()
+                for (const AtomRecord &atom : conf.atoms) {
+                    if (atom.element.empty()) {  // options.rs:164
+                        err = {SASACalcError::ElementMissing, "Element missing for atom"};
+                        return false;
+                    }
+                    if (atom.element == "H" && !o.include_hydrogens) continue;  // options.rs:166
+                    if (atom.hetero && !o.include_hetatms) continue;           // options.rs:169
+                    const std::uint64_t id =
+                        fnv_hash_altloc_serial(id_uses_altloc ? conf.alt_loc : std::string(), atom.serial);
+                    if (!build_atom(o, atom, residue_name, id, atoms, err)) return false;
+                }
+            }
+            per_residue(ci, ri, begin, atoms.size());
+        }
+    }
+    return true;
+}
+
+template <typename T>
+Result<T> fail(const BuildError &e)
+{
+    Result<T> r;
+    r.error = e.error;
+    r.message = e.message;
+    return r;
+}
+
+// per-atom SASA + sequential f32 sums of the given contiguous segments, all on the GPU
+struct HotPathOut {
+    std::vector<float> atom, segment;
+};
+
+Result<HotPathOut> run(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms,
+                       const std::vector<uint32_t> &segment_offsets)
+{
+    Result<HotPathOut> r;
+    const size_t n = atoms.size();
+    std::vector<float> x(n), y(n), z(n), rad(n);
+    std::vector<std::uint64_t> id(n);
+    for (size_t i = 0; i < n; i++) {
+        x[i] = atoms[i].position[0];
+        y[i] = atoms[i].position[1];
+        z[i] = atoms[i].position[2];
+        rad[i] = atoms[i].radius;
+        id[i] = atoms[i].id;
+    }
+    r.value.atom.assign(n, 0.f);
+    const size_t n_seg = segment_offsets.empty() ? 0 : segment_offsets.size() - 1;
+    r.value.segment.assign(n_seg, 0.f);
+    if (n == 0) return r;  // calculate_sasa_internal on an empty slice returns an empty Vec
+    const uint32_t so[2] = {0u, (uint32_t)n};
+    const int rc = rsasa_calculate_sasa_batch(o.context, x.data(), y.data(), z.data(), rad.data(),
+                                              id.data(), so, 1, o.probe_radius, o.n_points,
+                                              r.value.atom.data(),
+                                              n_seg ? segment_offsets.data() : nullptr, n_seg,
+                                              n_seg ? r.value.segment.data() : nullptr);
+    if (rc != RSASA_OK) {
+        r.error = SASACalcError::Engine;
+        r.message = std::string("rustsasa_amd engine: ") + rsasa_status_string(rc);
+        if (o.context) r.message += std::string(": ") + rsasa_context_last_error(o.context);
+    }
+    return r;
+}
+
+}  // namespace
+
+Result<std::vector<float>> run_hot_path(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms)
+{
+    Result<std::vector<float>> out;
+    auto r = run(o, atoms, {});
+    out.error = r.error;
+    out.message = r.message;
+    out.value = std::move(r.value.atom);
+    return out;
+}
+
+// AtomLevel (options.rs:139-190)
+template <>
+struct Processor<AtomLevel> {
+    static Result<std::vector<float>> process(const Structure &pdb, const OptionValues &o)
+    {
+        std::vector<rsasa_atom_t> atoms;
+        BuildError err;
+        if (!select_atoms(pdb, o, true, atoms, err, [](size_t, size_t, size_t, size_t) {}))
+            return fail<std::vector<float>>(err);
+        return run_hot_path(o, atoms);  // process_atoms: atom_sasa.to_vec()
+    }
+};
+
+// ResidueLevel (options.rs:192-287)
+template <>
+struct Processor<ResidueLevel> {
+    static Result<std::vector<ResidueResult>> process(const Structure &pdb, const OptionValues &o)
+    {
+        std::vector<rsasa_atom_t> atoms;
+        std::vector<uint32_t> offs{0u};
+        BuildError err;
+        if (!select_atoms(pdb, o, true, atoms, err,
+                          [&](size_t, size_t, size_t, size_t end) { offs.push_back((uint32_t)end); }))
+            return fail<std::vector<ResidueResult>>(err);
+        Result<std::vector<ResidueResult>> out;
+        auto r = run(o, atoms, offs);
+        if (!r.ok()) { out.error = r.error; out.message = r.message; return out; }
+        size_t k = 0;
+        for (const Chain &chain : pdb.chains)
+            for (const Residue &res : chain.residues) {
+                std::string name;
+                res.name(&name);
+                out.value.push_back(ResidueResult{res.serial_number, res.insertion_code,
+                                                  r.value.segment[k++], name, is_polar_residue(name),
+                                                  chain.id});
+            }
+        return out;
+    }
+};
+
+// ChainLevel (options.rs:289-365), including the serialize_chain_id key: chains
+// whose ids serialise to the same number share the map entry of the LAST of them.
+template <>
+struct Processor<ChainLevel> {
+    static Result<std::vector<ChainResult>> process(const Structure &pdb, const OptionValues &o)
+    {
+        std::vector<rsasa_atom_t> atoms;
+        std::vector<uint32_t> chain_end(pdb.chains.size(), 0u);
+        BuildError err;
+        if (!select_atoms(pdb, o, true, atoms, err,
+                          [&](size_t ci, size_t, size_t, size_t end) { chain_end[ci] = (uint32_t)end; }))
+            return fail<std::vector<ChainResult>>(err);
+        // kept atoms of a chain are contiguous; a chain without residues owns an empty range
+        std::vector<uint32_t> offs{0u};
+        for (size_t ci = 0; ci < pdb.chains.size(); ci++)
+            offs.push_back(std::max(offs.back(), chain_end[ci]));
+        Result<std::vector<ChainResult>> out;
+        auto r = run(o, atoms, offs);
+        if (!r.ok()) { out.error = r.error; out.message = r.message; return out; }
+        std::map<std::int64_t, size_t> key_to_chain;  // parent_to_atoms.insert overwrites
+        for (size_t ci = 0; ci < pdb.chains.size(); ci++) key_to_chain[serialize_chain_id(pdb.chains[ci].id)] = ci;
+        for (const Chain &chain : pdb.chains)
+            out.value.push_back(ChainResult{chain.id, r.value.segment[key_to_chain[serialize_chain_id(chain.id)]]});
+        return out;
+    }
+};
+
+// ProteinLevel (options.rs:367-464): ids ignore the alt-loc (:453).
+template <>
+struct Processor<ProteinLevel> {
+    static Result<ProteinResult> process(const Structure &pdb, const OptionValues &o)
+    {
+        std::vector<rsasa_atom_t> atoms;
+        std::vector<uint32_t> offs{0u};
+        BuildError err;
+        if (!select_atoms(pdb, o, false, atoms, err,
+                          [&](size_t, size_t, size_t, size_t end) { offs.push_back((uint32_t)end); }))
+            return fail<ProteinResult>(err);
+        Result<ProteinResult> out;
+        auto r = run(o, atoms, offs);
+        if (!r.ok()) { out.error = r.error; out.message = r.message; return out; }
+        float polar = 0.f, non_polar = 0.f;  // options.rs:376-402
+        size_t k = 0;
+        for (const Chain &chain : pdb.chains)
+            for (const Residue &res : chain.residues) {
+                std::string name;
+                res.name(&name);
+                if (is_polar_residue(name)) polar += r.value.segment[k]; else non_polar += r.value.segment[k];
+                k++;
+            }
+        // global_total = simd_sum(atom_sasa) (options.rs:404): one sequential f32 sum over all atoms
+        float global = 0.f;
+        if (!atoms.empty()) {
+            const uint32_t all[2] = {0u, (uint32_t)atoms.size()};
+            const int rc = rsasa_segment_sums(o.context, r.value.atom.data(), atoms.size(), all, 1, &global);
+            if (rc != RSASA_OK) {
+                out.error = SASACalcError::Engine;
+                out.message = std::string("rustsasa_amd engine: ") + rsasa_status_string(rc);
+                return out;
+            }
+        }
+        out.value = ProteinResult{global, polar, non_polar};
+        return out;
+    }
+};
+
+}  // namespace detail
+
+template <typename Level>
+Result<typename Level::Output> SASAOptions<Level>::process(const Structure &pdb) const
+{
+    return detail::Processor<Level>::process(pdb, o_);
+}
+
+template class SASAOptions<AtomLevel>;
+template class SASAOptions<ResidueLevel>;
+template class SASAOptions<ChainLevel>;
+template class SASAOptions<ProteinLevel>;
+
+}  // namespace rustsasa

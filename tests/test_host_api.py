@@ -1,0 +1,167 @@
+"""The C++ host API (include/rustsasa_amd.hpp: SASAOptions<Level>::process) driven
+through rustsasa_amd/lib/sasa_host_cli, checked against an independent Python
+restatement of the reference's level logic (src/options.rs) on top of the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import structio as sio
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
+FIXTURES = ["example.cif", "1jcd.pdb", "151L_H3.pdb", "bad_seqadv_1A06.pdb", "2drt.pdb"]
+POLAR = {"SER", "THR", "CYS", "ASN", "GLN", "TYR"}
+
+
+def run_cli(level, name, *opts, expect_rc=0):
+    p = subprocess.run([CLI, level, sio.data_path(name), *opts], capture_output=True, text=True)
+    assert p.returncode == expect_rc, (p.returncode, p.stdout[:300], p.stderr[:300])
+    return json.loads(p.stdout) if p.stdout.strip() else None
+
+
+def f32_seq_sum(values):
+    t = np.float32(0)
+    for v in values:
+        t = np.float32(t + np.float32(v))
+    return float(t)
+
+
+def residues_in_order(atoms):
+    """chains (first-appearance order) -> residues (first-appearance order) -> atom lists."""
+    chains, order = {}, []
+    for a in atoms:
+        if a.chain not in chains:
+            chains[a.chain] = ({}, [])
+            order.append(a.chain)
+        res, rorder = chains[a.chain]
+        key = (a.resseq, a.icode)
+        if key not in res:
+            res[key] = []
+            rorder.append(key)
+        res[key].append(a)
+    out = []
+    for c in order:
+        res, rorder = chains[c]
+        for key in rorder:
+            out.append((c, key, res[key]))
+    return out
+
+
+def expected(name, n_points=100, include_hetatms=False, vdw_fallback=False):
+    atoms = sio.read_structure(sio.data_path(name))
+    tab = sio.parse_protor(sio.data_path("protor.config"))
+    sel, res_offsets, res_meta, chain_of_res = [], [0], [], []
+    for chain, (resseq, icode), ratoms in residues_in_order(atoms):
+        first_conf = (ratoms[0].resname, ratoms[0].altloc)
+        for a in ratoms:
+            if (a.resname, a.altloc) != first_conf:
+                continue
+            if a.element == "H" or (a.hetero and not include_hetatms):
+                continue
+            r = tab.get((a.resname, a.name))
+            if r is None:
+                assert vdw_fallback, (a.resname, a.name)
+                r = sio.VDW[a.element]
+            sel.append((a, r))
+        res_offsets.append(len(sel))
+        res_meta.append((resseq, icode, ratoms[0].resname, chain))
+    x = np.array([a.x for a, _ in sel], np.float64).astype(np.float32)
+    y = np.array([a.y for a, _ in sel], np.float64).astype(np.float32)
+    z = np.array([a.z for a, _ in sel], np.float64).astype(np.float32)
+    r = np.array([rr for _, rr in sel], np.float32)
+    ids = np.array([a.serial for a, _ in sel], np.uint64)
+    atom = po.calculate_sasa_internal(x, y, z, r, ids, 1.4, n_points, 8)
+    res = po.residue_sums(atom, np.array(res_offsets, np.uint32))
+    return atom, res, res_meta
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_reader_counts_match_independent_parser(name):
+    atoms = sio.read_structure(sio.data_path(name))
+    got = run_cli("parse", name)
+    assert got["atoms"] == len(atoms)
+    assert got["chains"] == len({a.chain for a in atoms})
+    assert got["residues"] == len({(a.chain, a.resseq, a.icode) for a in atoms})
+
+
+def test_no_gpu_is_a_loud_engine_error():
+    import rustsasa_amd
+    if rustsasa_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    got = run_cli("atom", "1jcd.pdb", expect_rc=2)
+    assert got["error"] == 7 and "no usable HIP device" in got["message"]
+
+
+def test_radius_missing_is_reported_before_the_hot_path():
+    # HETATM ligands have no ProtOr entry: RadiusMissing unless vdW fallback is allowed
+    got = run_cli("atom", "2drt.pdb", "--include-hetatms", expect_rc=2)
+    assert got["error"] == 3 and "Radius not found for residue" in got["message"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FIXTURES)
+def test_atom_and_residue_levels(name):
+    atom, res, meta = expected(name)
+    got = run_cli("atom", name)["Atom"]
+    assert len(got) == len(atom)
+    assert np.array_equal(np.array(got, np.float32), atom)
+    got_res = run_cli("residue", name)["Residue"]
+    assert len(got_res) == len(meta)
+    for g, v, (resseq, icode, resname, chain) in zip(got_res, res, meta):
+        assert g["serial_number"] == resseq and g["insertion_code"] == icode
+        assert g["name"] == resname and g["chain_id"] == chain
+        assert g["is_polar"] == (resname in POLAR)
+        assert np.float32(g["value"]) == v
+    # residues made only of HETATM records are reported with 0.0 (reference tests/io.rs:165-224)
+    hetero_only = [g for g, (_, _, resname, _) in zip(got_res, meta) if resname == "HOH"]
+    assert all(g["value"] == 0.0 for g in hetero_only)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["example.cif", "1jcd.pdb"])
+def test_chain_and_protein_levels(name):
+    atom, res, meta = expected(name)
+    chains = []
+    for (_, _, _, c) in meta:
+        if c not in chains:
+            chains.append(c)
+    got = run_cli("chain", name)["Chain"]
+    assert [g["name"] for g in got] == chains
+    # atoms of a chain are contiguous: sequential f32 sum over them (options.rs:304-308)
+    offs = [0]
+    a_all = sio.read_structure(sio.data_path(name))
+    kept_chain = [a.chain for a in a_all if not a.hetero and a.element != "H"]
+    for c in chains:
+        offs.append(offs[-1] + sum(1 for k in kept_chain if k == c))
+    for g, b, e in zip(got, offs[:-1], offs[1:]):
+        assert np.float32(g["value"]) == np.float32(f32_seq_sum(atom[b:e]))
+    prot = run_cli("protein", name)["Protein"]
+    assert np.float32(prot["global_total"]) == np.float32(f32_seq_sum(atom))
+    polar = f32_seq_sum([v for v, m in zip(res, meta) if m[2] in POLAR])
+    non_polar = f32_seq_sum([v for v, m in zip(res, meta) if m[2] not in POLAR])
+    assert np.float32(prot["polar_total"]) == np.float32(polar)
+    assert np.float32(prot["non_polar_total"]) == np.float32(non_polar)
+
+
+@pytest.mark.gpu
+def test_reference_literals_within_their_own_tolerance():
+    """tests/units.rs:58,76,89 (+-1500): example.cif, 1A06 and 151L protein totals."""
+    for name, literal in (("example.cif", 20268.004), ("bad_seqadv_1A06.pdb", 14466.709),
+                          ("151L_H3.pdb", 9558.812)):
+        prot = run_cli("protein", name)["Protein"]
+        assert abs(prot["global_total"] - literal) <= 1500.0
+    hi = run_cli("protein", "example.cif", "--n-points", "960")["Protein"]
+    assert abs(hi["global_total"] - 20131.227) <= 1500.0
+    assert abs(hi["polar_total"] - 4279.8906) <= 1500.0
+    assert abs(hi["non_polar_total"] - 15999.43) <= 1500.0
+
+
+@pytest.mark.gpu
+def test_options_hetatms_with_vdw_fallback_and_points():
+    atom, _, _ = expected("2drt.pdb", n_points=200, include_hetatms=True, vdw_fallback=True)
+    got = run_cli("atom", "2drt.pdb", "--include-hetatms", "--allow-vdw-fallback", "--n-points", "200")["Atom"]
+    assert np.array_equal(np.array(got, np.float32), atom)
