@@ -153,8 +153,14 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
     auto it = ctx->lattices.find(key);
     if (it == ctx->lattices.end()) {
         const uint32_t padded = (uint32_t)((n_points + 63) / 64 * 64);
-        std::vector<float> h(3 * (size_t)padded, 0.0f);
+        std::vector<float> h(7 * (size_t)padded, 0.0f);  // x | y | z | (x, y, z, 0) records
         generate_sphere_points(n_points, h.data(), h.data() + padded, h.data() + 2 * (size_t)padded);
+        for (size_t i = 0; i < n_points; i++) {
+            float *r4 = h.data() + 3 * (size_t)padded + 4 * i;
+            r4[0] = h[i];
+            r4[1] = h[padded + i];
+            r4[2] = h[2 * (size_t)padded + i];
+        }
         LatticeEntry e;
         e.padded = padded;
         RS_HIP(ctx, hipMalloc((void **)&e.d, h.size() * sizeof(float)));
@@ -168,6 +174,7 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
     out->x = it->second.d;
     out->y = it->second.d + it->second.padded;
     out->z = it->second.d + 2 * (size_t)it->second.padded;
+    out->xyz4 = (const float4 *)(it->second.d + 3 * (size_t)it->second.padded);
     out->n_points = (uint32_t)n_points;
     out->n_fused = (uint32_t)(n_points - n_points % (size_t)ctx->simd_width);
     return RSASA_OK;

@@ -47,6 +47,7 @@ struct BatchStatus {
 
 struct Lattice {
     const float *x, *y, *z;  // device SoA, padded with zeros to a multiple of 64 entries
+    const float4 *xyz4;      // the same points as (x, y, z, 0) records
     uint32_t n_points;
     uint32_t n_fused;        // points [0, n_fused) use the fused-FMA `<` rule (lib.rs:143-146);
                              // the rest the scalar remainder rule (lib.rs:185-186,206-207)
@@ -82,7 +83,7 @@ struct BatchView {
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
-    int kernel_version = 2;       // 0 = all-pairs kernel, 1 = near/far two-phase, 2 = tiled two-phase
+    int kernel_version = 3;       // 0 = all-pairs kernel, 2 = tiled two-phase, 3 = tiled two-phase, lean
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
 };
 

@@ -51,263 +51,6 @@ __device__ __forceinline__ float readlane_f(float v, int l)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-template <int NCH, bool HAS_ID>
-__global__ __launch_bounds__(256) void k_occlusion_v1(OccArgs a)
-{
-    const BatchView &b = a.b;
-    if (batch_aborted(b.status)) return;
-    __shared__ float4 s_cand[4][kCap];
-    __shared__ int s_delta[4][32];     // per non-empty run: start - exclusive prefix
-    __shared__ uint32_t s_mask[4][8];  // run-start markers of a 256-position super-window
-
-    const uint32_t lane = lane_id();
-    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t bid = blockIdx.x;
-    {
-        const uint32_t per = a.n_blocks / 8u;
-        if (bid < per * 8u) bid = (bid % 8u) * per + bid / 8u;
-    }
-    const uint32_t apw = a.atoms_per_wave;
-    const uint32_t p_begin = (bid * 4u + w) * apw;
-    if (p_begin >= b.n_atoms) return;
-    const uint32_t p_end = min(p_begin + apw, b.n_atoms);
-
-    const float probe = b.probe;
-    const uint32_t n_points = a.lat.n_points;
-    const uint32_t n_chunks = (n_points + kWave - 1) / kWave;
-    const bool counting = b.neighbor_counts != nullptr;
-    const float neg_inf = __int_as_float(0xFF800000);
-
-    float sx[NCH], sy[NCH], sz[NCH];
-    unsigned long long invalid[NCH], rem[NCH];
-    auto load_group = [&](uint32_t ch0) {
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const uint32_t pi = (ch0 + c) * kWave + lane;  // lattice arrays are zero padded
-            const bool in_range = (ch0 + c) < n_chunks;
-            sx[c] = in_range ? a.lat.x[pi] : 0.0f;
-            sy[c] = in_range ? a.lat.y[pi] : 0.0f;
-            sz[c] = in_range ? a.lat.z[pi] : 0.0f;
-            invalid[c] = __ballot(!(in_range && pi < n_points));
-            rem[c] = __ballot(in_range && pi >= a.lat.n_fused && pi < n_points);
-        }
-    };
-    const bool single_group = n_chunks <= (uint32_t)NCH;
-    if (single_group) load_group(0);
-
-    for (uint32_t p = p_begin; p < p_end; p++) {
-        const float4 me = b.sorted_xyzr[p];
-        const StructGrid g = b.grids[b.sid[p]];
-        const float R = me.w + probe;                    // lib.rs:101
-        const float R2 = R * R;                          // lib.rs:102
-        const float twoR = 2.0f * R;                     // lib.rs:136
-        const float sr = me.w + g.max_r + 2.0f * probe;  // spatial_grid.rs:307
-        const float sr2 = sr * sr;                       // spatial_grid.rs:308
-        unsigned long long my_id = 0;
-        if (HAS_ID) my_id = b.sorted_id[p];
-
-        // -- 1. x-runs of the 5x5x5 block, culled by a lower bound on the distance
-        const float fx = (me.x - g.min_x) * g.inv_cell;  // spatial_grid.rs:139-141
-        const float fy = (me.y - g.min_y) * g.inv_cell;
-        const float fz = (me.z - g.min_z) * g.inv_cell;
-        const uint32_t cx = min(f2u_sat(fx), g.dim_x - 1u);
-        const uint32_t cy = min(f2u_sat(fy), g.dim_y - 1u);
-        const uint32_t cz = min(f2u_sat(fz), g.dim_z - 1u);
-        // |f_i - f_j| (cell units, as computed) bounds the true separation up to the rounding
-        // of the two f values; `tol` covers that, the factor on srn^2 covers inv_cell's rounding.
-        const float tol = 8.0f * 1.1920929e-7f * fmaxf(fmaxf(fabsf(fx), fabsf(fy)), fabsf(fz)) + 1e-5f;
-        const float srn = sr * g.inv_cell;
-        const float thr = srn * srn * 1.00001f;
-        uint32_t run_start = 0, run_len = 0;
-        if (lane < 25) {
-            const int dy = (int)(lane % 5u) - 2, dz = (int)(lane / 5u) - 2;
-            const int yy = (int)cy + dy, zz = (int)cz + dz;
-            float gy = dy > 0 ? (float)yy - fy : (dy < 0 ? fy - (float)(yy + 1) : 0.0f);
-            float gz = dz > 0 ? (float)zz - fz : (dz < 0 ? fz - (float)(zz + 1) : 0.0f);
-            gy = fmaxf(gy - tol, 0.0f);
-            gz = fmaxf(gz - tol, 0.0f);
-            const float b2 = thr - gy * gy - gz * gz;
-            if (yy >= 0 && yy < (int)g.dim_y && zz >= 0 && zz < (int)g.dim_z && b2 >= 0.0f) {
-                const float gl = fx - (float)cx, gr = (float)(cx + 1u) - fx;
-                const float gl1 = fmaxf(gl - tol, 0.0f);         // to cell cx-1
-                const float gl2 = fmaxf(gl + 1.0f - tol, 0.0f);  // to cell cx-2
-                const float gr1 = fmaxf(gr - tol, 0.0f);         // to cell cx+1
-                const float gr2 = fmaxf(gr + 1.0f - tol, 0.0f);  // to cell cx+2
-                const int lo = gl2 * gl2 <= b2 ? 2 : (gl1 * gl1 <= b2 ? 1 : 0);
-                const int hi = gr2 * gr2 <= b2 ? 2 : (gr1 * gr1 <= b2 ? 1 : 0);
-                const uint32_t x0 = (uint32_t)max((int)cx - lo, 0);
-                const uint32_t x1 = min(cx + (uint32_t)hi, g.dim_x - 1u);
-                const uint32_t c0 = g.cell_base + x0 + (uint32_t)yy * g.dim_x +
-                                    (uint32_t)zz * g.dim_x * g.dim_y;
-                run_start = b.cells[c0];
-                run_len = b.cells[c0 + (x1 - x0) + 1u] - run_start;
-            }
-        }
-        const uint32_t run_incl = wave_incl_scan(run_len);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)run_incl, 31);
-        const uint32_t run_excl = run_incl - run_len;
-        const bool run_ne = run_len > 0;
-        {
-            const unsigned long long ne_mask = __ballot(run_ne);
-            if (run_ne) s_delta[w][mbcnt64(ne_mask)] = (int)run_start - (int)run_excl;
-        }
-
-        float accessible = 0.0f;
-        uint32_t k_total = 0;
-
-        for (uint32_t ch0 = 0; ch0 < n_chunks; ch0 += NCH) {
-            if (!single_group) load_group(ch0);
-            unsigned long long occ[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; c++) occ[c] = invalid[c];
-
-            uint32_t nA = 0, nB = 0;
-            bool done = false;  // every point occluded: nothing left to decide
-
-            for (uint32_t sw0 = 0; sw0 < total && !done; sw0 += 256u) {
-                // run-start markers for flat positions [sw0, sw0 + 256)
-                if (lane < 8) s_mask[w][lane] = 0u;
-                wave_lds_fence();
-                if (run_ne && run_excl >= sw0 && run_excl < sw0 + 256u)
-                    atomicOr(&s_mask[w][(run_excl - sw0) >> 5], 1u << ((run_excl - sw0) & 31u));
-                wave_lds_fence();
-                const uint32_t mword = lane < 8 ? s_mask[w][lane] : 0u;
-                uint32_t base_rank = (uint32_t)__popcll(__ballot(run_ne && run_excl < sw0));
-
-#pragma unroll
-                for (int win = 0; win < 4; win++) {
-                    const uint32_t f0 = sw0 + (uint32_t)win * 64u;
-                    if (f0 >= total || done) break;
-                    const unsigned long long mask64 =
-                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mword, 2 * win) |
-                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mword, 2 * win + 1) << 32);
-                    // index of the run that contains flat position f = f0 + lane
-                    const uint32_t rnk = base_rank + (uint32_t)(mask64 & 1ull) + mbcnt64(mask64 >> 1) - 1u;
-                    base_rank += (uint32_t)__popcll(mask64);
-
-                    // -- 2. sweep 64 atoms of the block
-                    const uint32_t f = f0 + lane;
-                    bool accept = false, near = false;
-                    float4 cand = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (f < total) {
-                        const uint32_t q = (uint32_t)((int)f + s_delta[w][rnk]);
-                        const float4 o = b.sorted_xyzr[q];
-                        const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;  // lib.rs:129-131
-                        const float d2 = dx * dx + dy * dy + dz * dz;  // spatial_grid.rs:321 == lib.rs:132
-                        accept = (q != p) && (d2 <= sr2);              // spatial_grid.rs:335
-                        if (HAS_ID) {
-                            if (accept) accept = b.sorted_id[q] != my_id;  // spatial_grid.rs:314
-                        }
-                        const float Rj = o.w + probe;                  // spatial_grid.rs:336
-                        const float hs = 0.5f * (R + Rj);
-                        near = accept && d2 < hs * hs;                 // heuristic only
-                        cand = make_float4(dx, dy, dz, Rj);
-                    }
-                    const unsigned long long mN = __ballot(near);
-                    const unsigned long long mF = __ballot(accept && !near);
-                    if (accept) {
-                        const uint32_t slot = near ? nA + mbcnt64(mN) : (uint32_t)kCap - 1u - (nB + mbcnt64(mF));
-                        s_cand[w][slot] = cand;
-                    }
-                    nA += (uint32_t)__popcll(mN);
-                    nB += (uint32_t)__popcll(mF);
-                    const bool last = f0 + 64u >= total;
-                    if (nA + nB <= (uint32_t)kFlushAt && !last) continue;
-
-                    // ---- flush: decide points against the queued candidates ----
-                    const uint32_t K = nA + nB;
-                    if (ch0 == 0) k_total += K;
-                    wave_lds_fence();
-                    // -- 3. prep: limit_j for every queued candidate (lane = candidate)
-                    float cvx = 0.f, cvy = 0.f, cvz = 0.f, clim = neg_inf;
-                    for (uint32_t k0 = 0; k0 < K; k0 += 64u) {
-                        const uint32_t k = k0 + lane;
-                        float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-                        float lim = neg_inf;
-                        if (k < K) {
-                            const uint32_t slot = k < nA ? k : (uint32_t)kCap - K + k;
-                            e = s_cand[w][slot];
-                            const float d2 = e.x * e.x + e.y * e.y + e.z * e.z;  // lib.rs:132-133
-                            const float t = e.w * e.w;                           // spatial_grid.rs:339
-                            lim = (t - d2 - R2) / twoR;                          // lib.rs:136
-                            s_cand[w][slot].w = lim;
-                        }
-                        if (k0 == 0) { cvx = e.x; cvy = e.y; cvz = e.z; clim = lim; }
-                    }
-                    wave_lds_fence();
-                    // -- 4. phase A: near candidates against all fused-rule points (lane = point)
-                    bool any_left = true;
-                    for (uint32_t k = 0; k < nA; k++) {
-                        const float4 cd = s_cand[w][k];
-                        unsigned long long all = ~0ull;
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) {
-                            // lib.rs:143-146: mul_add(sx, vx, mul_add(sy, vy, sz * vz)) < limit
-                            const float dot = __builtin_fmaf(sx[c], cd.x, __builtin_fmaf(sy[c], cd.y, sz[c] * cd.z));
-                            occ[c] |= __ballot(dot < cd.w) & ~rem[c];
-                            all &= occ[c];
-                        }
-                        if (all == ~0ull) { any_left = false; break; }  // lib.rs:149-152
-                    }
-                    // -- 5. phase B: surviving points against all candidates (lane = candidate)
-                    if (any_left) {
-                        for (uint32_t k0 = 0; k0 < K; k0 += 64u) {
-                            if (k0 > 0) {
-                                const uint32_t k = k0 + lane;
-                                cvx = cvy = cvz = 0.f;
-                                clim = neg_inf;
-                                if (k < K) {
-                                    const float4 e = s_cand[w][k < nA ? k : (uint32_t)kCap - K + k];
-                                    cvx = e.x; cvy = e.y; cvz = e.z; clim = e.w;
-                                }
-                            }
-#pragma unroll
-                            for (int c = 0; c < NCH; c++) {
-                                unsigned long long surv = ~occ[c];
-                                while (surv) {
-                                    const int pl = __builtin_ctzll(surv);
-                                    surv &= surv - 1ull;
-                                    const float px = readlane_f(sx[c], pl), py = readlane_f(sy[c], pl),
-                                                pz = readlane_f(sz[c], pl);
-                                    bool hit;
-                                    if (!((rem[c] >> pl) & 1ull)) {
-                                        // lib.rs:143-146
-                                        hit = __builtin_fmaf(px, cvx, __builtin_fmaf(py, cvy, pz * cvz)) < clim;
-                                    } else {
-                                        // lib.rs:185-186,206-207: plain products, `<=`
-                                        hit = (px * cvx + py * cvy + pz * cvz) <= clim;
-                                    }
-                                    if (__ballot(hit) != 0ull) occ[c] |= 1ull << pl;
-                                }
-                            }
-                        }
-                    }
-                    wave_lds_fence();
-                    nA = nB = 0;
-                    if (!counting) {
-                        unsigned long long all = ~0ull;
-#pragma unroll
-                        for (int c = 0; c < NCH; c++) all &= occ[c];
-                        done = (all == ~0ull);
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; c++) accessible += (float)__popcll(~occ[c]);  // lib.rs:156-159
-        }
-
-        if (lane == 0) {
-            const uint32_t orig = b.sorted_orig[p];
-            const float surface_area = (4.0f * 3.14159274101257324219f) * R2;  // 4.0 * PI * r2, lib.rs:220
-            const float inv_n = 1.0f / (float)n_points;                        // lib.rs:221
-            b.atom_sasa[orig] = surface_area * accessible * inv_n;             // lib.rs:222
-            if (counting) b.neighbor_counts[orig] = k_total;
-        }
-        wave_lds_fence();
-    }
-}
-
-
 // ------------------------------------------------------------------ v2 ----
 //
 // Same mathematics as v1, restructured to cut scalar-ALU and per-iteration
@@ -647,6 +390,8 @@ __global__ __launch_bounds__(256) void k_occlusion_v2(OccArgs a)
     }
 }
 
+#include "occlusion_v3.inc"
+
 template <int NCH>
 void launch_occ(const OccArgs &a, int version, hipStream_t stream)
 {
@@ -654,9 +399,10 @@ void launch_occ(const OccArgs &a, int version, hipStream_t stream)
     if (version == 0) {
         if (id) hipLaunchKernelGGL((k_occlusion_v0<NCH, true>), dim3(a.n_blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_occlusion_v0<NCH, false>), dim3(a.n_blocks), dim3(256), 0, stream, a);
-    } else if (version == 1) {
-        if (id) hipLaunchKernelGGL((k_occlusion_v1<NCH, true>), dim3(a.n_blocks), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((k_occlusion_v1<NCH, false>), dim3(a.n_blocks), dim3(256), 0, stream, a);
+    } else if (version == 3) {
+        const OccArgs3 a3 = make_args3(a);
+        if (id) hipLaunchKernelGGL((k_occlusion_v3<NCH, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        else hipLaunchKernelGGL((k_occlusion_v3<NCH, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
     } else {
         if (id) hipLaunchKernelGGL((k_occlusion_v2<NCH, true>), dim3(a.n_blocks), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL((k_occlusion_v2<NCH, false>), dim3(a.n_blocks), dim3(256), 0, stream, a);

@@ -308,9 +308,9 @@ def test_full_proteome_properties(ctx):
 
 
 @pytest.mark.parametrize("env", [{"RSASA_OCCLUSION_KERNEL": "0"},
-                                 {"RSASA_OCCLUSION_KERNEL": "1", "RSASA_ATOMS_PER_WAVE": "7"},
-                                 {"RSASA_OCCLUSION_KERNEL": "2", "RSASA_ATOMS_PER_WAVE": "1"},
-                                 {"RSASA_OCCLUSION_KERNEL": "2", "RSASA_ATOMS_PER_WAVE": "5"}])
+                                 {"RSASA_OCCLUSION_KERNEL": "2", "RSASA_ATOMS_PER_WAVE": "5"},
+                                 {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "1"},
+                                 {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "7"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """Every occlusion kernel variant / wave schedule gives bit-identical results."""
     import rustsasa_amd
