@@ -141,10 +141,24 @@ struct OptionValues {
     rsasa_context_t *context = nullptr;      // GPU context; nullptr = the library's default (device 0)
 };
 
+// Wall-clock split of SASAOptions::process_files.
+struct FilesTimings {
+    double parse_seconds = 0;    // reading + parsing + atom selection on the host threads
+    double compute_seconds = 0;  // packing, H2D, GPU hot path, D2H, result mapping
+    double total_seconds = 0;
+    std::size_t n_files = 0, n_atoms = 0;
+};
+
 namespace detail {
-template <typename Level>
-struct Processor;  // build_atoms_and_mapping / process_atoms per level (options.rs:139-464)
 Result<std::vector<float>> run_hot_path(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms);
+template <typename Level>
+std::vector<Result<typename Level::Output>> process_many(const std::vector<const Structure *> &pdbs,
+                                                         const OptionValues &o);
+template <typename Level>
+std::vector<Result<typename Level::Output>> process_files(const std::vector<std::string> &paths,
+                                                          const OptionValues &o, unsigned host_threads,
+                                                          std::size_t files_per_batch,
+                                                          FilesTimings *timings);
 }  // namespace detail
 
 template <typename Level>
@@ -169,6 +183,15 @@ public:
     // options.rs:606-618
     Result<typename Level::Output> process(const Structure &pdb) const;
 
+    // Directory mode at library level (reference src/main.rs:342-480, `files.par_iter()` :375):
+    // parse + select on `host_threads` threads (0 = all), then ONE GPU batch per
+    // `files_per_batch` structures (0 = 4096).  A file that fails (unreadable, missing radius,
+    // ...) gets its own error; the others are unaffected (main.rs:446-454).
+    std::vector<Result<typename Level::Output>> process_files(const std::vector<std::string> &paths,
+                                                              unsigned host_threads = 0,
+                                                              std::size_t files_per_batch = 0,
+                                                              FilesTimings *timings = nullptr) const;
+
 private:
     OptionValues o_;
 };
@@ -177,6 +200,9 @@ extern template class SASAOptions<AtomLevel>;
 extern template class SASAOptions<ResidueLevel>;
 extern template class SASAOptions<ChainLevel>;
 extern template class SASAOptions<ProteinLevel>;
+
+// The reader's decimal parser (exact: equals strtod on every input); exposed for tests.
+double parse_decimal_text(const std::string &text);
 
 // helpers shared with the reference's utils.rs
 std::int64_t serialize_chain_id(const std::string &s);                  // utils.rs:24-33

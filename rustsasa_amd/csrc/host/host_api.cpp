@@ -5,12 +5,16 @@
 #include "../../../include/rustsasa_amd.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
+#include <type_traits>
 
 namespace rustsasa {
 
@@ -216,6 +220,73 @@ std::string field(const std::string &line, size_t from, size_t to)  // 1-based i
     return trim(line.substr(from - 1, std::min(to, line.size()) - from + 1));
 }
 
+// Decimal text -> double.  Plain decimals with at most 15 significant digits (every PDB
+// %8.3f field, typical mmCIF Cartn values) take Clinger's exact fast path: an integer below
+// 2^53 divided by a power of ten below 10^22 is one correctly rounded IEEE division, so the
+// result equals strtod's.  Anything else (exponents, long mantissas, garbage) goes to strtod.
+double parse_decimal(const char *p, size_t n)
+{
+    static const double pow10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                   1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char *b = p, *e = p + n;
+    while (b < e && (*b == ' ' || *b == '\t')) b++;
+    while (e > b && (e[-1] == ' ' || e[-1] == '\t')) e--;
+    const char *q = b;
+    bool neg = false;
+    if (q < e && (*q == '-' || *q == '+')) neg = (*q++ == '-');
+    unsigned long long mant = 0;
+    int digits = 0, frac = 0;
+    bool seen_dot = false, ok = q < e;
+    for (; q < e; q++) {
+        const char c = *q;
+        if (c >= '0' && c <= '9') {
+            if (mant != 0 || c != '0') digits++;
+            mant = mant * 10 + (unsigned)(c - '0');
+            if (seen_dot) frac++;
+        } else if (c == '.' && !seen_dot) {
+            seen_dot = true;
+        } else {
+            ok = false;
+            break;
+        }
+        if (digits > 15) { ok = false; break; }
+    }
+    if (ok && frac <= 22) {
+        const double v = (double)mant / pow10[frac];
+        return neg ? -v : v;
+    }
+    return std::strtod(std::string(b, (size_t)(e - b)).c_str(), nullptr);
+}
+
+inline double column_decimal(const std::string &line, size_t from, size_t to, double missing)
+{
+    if (line.size() < from) return missing;
+    const size_t len = std::min(to, line.size()) - from + 1;
+    const char *p = line.data() + from - 1;
+    bool blank = true;
+    for (size_t i = 0; i < len; i++) blank = blank && (p[i] == ' ');
+    return blank ? missing : parse_decimal(p, len);
+}
+
+inline long column_int(const std::string &line, size_t from, size_t to, bool *ok)
+{
+    long v = 0;
+    bool neg = false, any = false, good = true;
+    if (line.size() >= from) {
+        const size_t end = std::min(to, line.size());
+        for (size_t i = from - 1; i < end; i++) {
+            const char c = line[i];
+            if (c == ' ') { if (any) { for (size_t j = i; j < end; j++) good = good && line[j] == ' '; break; } continue; }
+            if (c == '-' && !any && !neg) { neg = true; continue; }
+            if (c < '0' || c > '9') { good = false; break; }
+            v = v * 10 + (c - '0');
+            any = true;
+        }
+    }
+    if (ok) *ok = good && any;
+    return neg ? -v : v;
+}
+
 // mmCIF tokenizer for one line: whitespace separated, '...' and "..." quoting.
 void tokenize(const std::string &line, std::vector<std::string> &out)
 {
@@ -241,6 +312,8 @@ void tokenize(const std::string &line, std::vector<std::string> &out)
 
 }  // namespace
 
+double parse_decimal_text(const std::string &text) { return parse_decimal(text.data(), text.size()); }
+
 Structure Structure::from_pdb_text(const std::string &text)
 {
     Structure s;
@@ -262,22 +335,20 @@ Structure Structure::from_pdb_text(const std::string &text)
         FlatAtom a;
         counter++;
         a.rec.hetero = is_het;
-        const std::string serial = field(line, 7, 11);
-        char *end = nullptr;
-        long sv = std::strtol(serial.c_str(), &end, 10);
-        a.rec.serial = (end && *end == '\0' && !serial.empty()) ? (std::size_t)sv : counter;
+        bool serial_ok = false;
+        const long sv = column_int(line, 7, 11, &serial_ok);
+        a.rec.serial = serial_ok ? (std::size_t)sv : counter;
         a.rec.name = field(line, 13, 16);
         a.alt = field(line, 17, 17);
         a.res_name = field(line, 18, 20);
         a.chain = field(line, 22, 22);
-        a.res_seq = std::strtol(field(line, 23, 26).c_str(), nullptr, 10);
+        a.res_seq = column_int(line, 23, 26, nullptr);
         a.icode = field(line, 27, 27);
-        a.rec.x = std::strtod(field(line, 31, 38).c_str(), nullptr);
-        a.rec.y = std::strtod(field(line, 39, 46).c_str(), nullptr);
-        a.rec.z = std::strtod(field(line, 47, 54).c_str(), nullptr);
-        const std::string occ = field(line, 55, 60), bf = field(line, 61, 66);
-        a.rec.occupancy = occ.empty() ? 1.0 : std::strtod(occ.c_str(), nullptr);
-        a.rec.b_factor = bf.empty() ? 0.0 : std::strtod(bf.c_str(), nullptr);
+        a.rec.x = column_decimal(line, 31, 38, 0.0);
+        a.rec.y = column_decimal(line, 39, 46, 0.0);
+        a.rec.z = column_decimal(line, 47, 54, 0.0);
+        a.rec.occupancy = column_decimal(line, 55, 60, 1.0);
+        a.rec.b_factor = column_decimal(line, 61, 66, 0.0);
         a.rec.element = upper(field(line, 77, 78));
         if (a.rec.element.empty()) a.rec.element = element_from_name(a.rec.name);
         add_atom(s, a);
@@ -351,11 +422,15 @@ Structure Structure::from_mmcif_text(const std::string &text)
         const std::string seq = c_aseq >= 0 && !val(c_aseq).empty() ? val(c_aseq) : val(c_lseq);
         a.res_seq = std::strtol(seq.c_str(), nullptr, 10);
         a.icode = val(c_ins);
-        a.rec.x = std::strtod(val(c_x).c_str(), nullptr);
-        a.rec.y = std::strtod(val(c_y).c_str(), nullptr);
-        a.rec.z = std::strtod(val(c_z).c_str(), nullptr);
-        a.rec.occupancy = val(c_occ).empty() ? 1.0 : std::strtod(val(c_occ).c_str(), nullptr);
-        a.rec.b_factor = val(c_b).empty() ? 0.0 : std::strtod(val(c_b).c_str(), nullptr);
+        auto num = [&](int c, double missing) {
+            if (c < 0 || c >= (int)tok.size() || tok[c] == "." || tok[c] == "?") return missing;
+            return parse_decimal(tok[c].data(), tok[c].size());
+        };
+        a.rec.x = num(c_x, 0.0);
+        a.rec.y = num(c_y, 0.0);
+        a.rec.z = num(c_z, 0.0);
+        a.rec.occupancy = num(c_occ, 1.0);
+        a.rec.b_factor = num(c_b, 0.0);
         a.rec.element = upper(val(c_sym));
         if (a.rec.element.empty()) a.rec.element = element_from_name(a.rec.name);
         add_atom(s, a);
@@ -465,50 +540,186 @@ bool select_atoms(const Structure &pdb, const OptionValues &o, bool id_uses_altl
     return true;
 }
 
-template <typename T>
-Result<T> fail(const BuildError &e)
-{
-    Result<T> r;
-    r.error = e.error;
-    r.message = e.message;
-    return r;
-}
-
-// per-atom SASA + sequential f32 sums of the given contiguous segments, all on the GPU
-struct HotPathOut {
-    std::vector<float> atom, segment;
+// What one structure contributes to a batch: its kept atoms and the contiguous atom
+// segments (residues or chains, by level) whose sequential f32 sums the level reports.
+struct Prepared {
+    BuildError err;
+    std::vector<rsasa_atom_t> atoms;
+    std::vector<uint32_t> seg_end;  // end offset (in `atoms`) of each segment, in output order
 };
 
-Result<HotPathOut> run(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms,
-                       const std::vector<uint32_t> &segment_offsets)
+// build_atoms_and_mapping of each level (options.rs:151-189, 234-286, 317-364, 412-463)
+template <typename Level>
+Prepared prepare(const Structure &pdb, const OptionValues &o);
+
+template <>
+Prepared prepare<AtomLevel>(const Structure &pdb, const OptionValues &o)
 {
-    Result<HotPathOut> r;
-    const size_t n = atoms.size();
-    std::vector<float> x(n), y(n), z(n), rad(n);
-    std::vector<std::uint64_t> id(n);
-    for (size_t i = 0; i < n; i++) {
-        x[i] = atoms[i].position[0];
-        y[i] = atoms[i].position[1];
-        z[i] = atoms[i].position[2];
-        rad[i] = atoms[i].radius;
-        id[i] = atoms[i].id;
+    Prepared p;
+    select_atoms(pdb, o, true, p.atoms, p.err, [](size_t, size_t, size_t, size_t) {});
+    return p;
+}
+
+template <>
+Prepared prepare<ResidueLevel>(const Structure &pdb, const OptionValues &o)
+{
+    Prepared p;
+    select_atoms(pdb, o, true, p.atoms, p.err,
+                 [&](size_t, size_t, size_t, size_t end) { p.seg_end.push_back((uint32_t)end); });
+    return p;
+}
+
+template <>
+Prepared prepare<ChainLevel>(const Structure &pdb, const OptionValues &o)
+{
+    Prepared p;
+    std::vector<uint32_t> chain_end(pdb.chains.size(), 0u);
+    select_atoms(pdb, o, true, p.atoms, p.err,
+                 [&](size_t ci, size_t, size_t, size_t end) { chain_end[ci] = (uint32_t)end; });
+    // kept atoms of a chain are contiguous; a chain without residues owns an empty range
+    uint32_t prev = 0;
+    for (size_t ci = 0; ci < pdb.chains.size(); ci++) {
+        prev = std::max(prev, chain_end[ci]);
+        p.seg_end.push_back(prev);
     }
-    r.value.atom.assign(n, 0.f);
-    const size_t n_seg = segment_offsets.empty() ? 0 : segment_offsets.size() - 1;
-    r.value.segment.assign(n_seg, 0.f);
-    if (n == 0) return r;  // calculate_sasa_internal on an empty slice returns an empty Vec
-    const uint32_t so[2] = {0u, (uint32_t)n};
-    const int rc = rsasa_calculate_sasa_batch(o.context, x.data(), y.data(), z.data(), rad.data(),
-                                              id.data(), so, 1, o.probe_radius, o.n_points,
-                                              r.value.atom.data(),
-                                              n_seg ? segment_offsets.data() : nullptr, n_seg,
-                                              n_seg ? r.value.segment.data() : nullptr);
-    if (rc != RSASA_OK) {
-        r.error = SASACalcError::Engine;
-        r.message = std::string("rustsasa_amd engine: ") + rsasa_status_string(rc);
-        if (o.context) r.message += std::string(": ") + rsasa_context_last_error(o.context);
+    return p;
+}
+
+template <>
+Prepared prepare<ProteinLevel>(const Structure &pdb, const OptionValues &o)
+{
+    Prepared p;  // ids ignore the alt-loc (options.rs:453)
+    select_atoms(pdb, o, false, p.atoms, p.err,
+                 [&](size_t, size_t, size_t, size_t end) { p.seg_end.push_back((uint32_t)end); });
+    return p;
+}
+
+// process_atoms of each level (options.rs:142-149, 195-232, 292-315, 370-410).  `atom` and
+// `seg` are this structure's slices of the batch results; `global` is the sequential f32 sum
+// over all its atoms (used by ProteinLevel only).
+template <typename Level>
+typename Level::Output finish(const Structure &pdb, const float *atom, size_t n_atoms,
+                              const float *seg, float global);
+
+template <>
+std::vector<float> finish<AtomLevel>(const Structure &, const float *atom, size_t n, const float *, float)
+{
+    return std::vector<float>(atom, atom + n);
+}
+
+template <>
+std::vector<ResidueResult> finish<ResidueLevel>(const Structure &pdb, const float *, size_t,
+                                                const float *seg, float)
+{
+    std::vector<ResidueResult> out;
+    size_t k = 0;
+    for (const Chain &chain : pdb.chains)
+        for (const Residue &res : chain.residues) {
+            std::string name;
+            res.name(&name);
+            out.push_back(ResidueResult{res.serial_number, res.insertion_code, seg[k++], name,
+                                        is_polar_residue(name), chain.id});
+        }
+    return out;
+}
+
+// ChainLevel keeps the serialize_chain_id key: chains whose ids serialise to the same number
+// share the map entry of the LAST of them (parent_to_atoms.insert overwrites, options.rs:361).
+template <>
+std::vector<ChainResult> finish<ChainLevel>(const Structure &pdb, const float *, size_t,
+                                            const float *seg, float)
+{
+    std::map<std::int64_t, size_t> key_to_chain;
+    for (size_t ci = 0; ci < pdb.chains.size(); ci++)
+        key_to_chain[serialize_chain_id(pdb.chains[ci].id)] = ci;
+    std::vector<ChainResult> out;
+    for (const Chain &chain : pdb.chains)
+        out.push_back(ChainResult{chain.id, seg[key_to_chain[serialize_chain_id(chain.id)]]});
+    return out;
+}
+
+template <>
+ProteinResult finish<ProteinLevel>(const Structure &pdb, const float *, size_t, const float *seg,
+                                   float global)
+{
+    float polar = 0.f, non_polar = 0.f;  // options.rs:376-402
+    size_t k = 0;
+    for (const Chain &chain : pdb.chains)
+        for (const Residue &res : chain.residues) {
+            std::string name;
+            res.name(&name);
+            if (is_polar_residue(name)) polar += seg[k]; else non_polar += seg[k];
+            k++;
+        }
+    return ProteinResult{global, polar, non_polar};  // global_total = simd_sum(atom_sasa), :404
+}
+
+std::string engine_message(const OptionValues &o, int rc)
+{
+    std::string m = std::string("rustsasa_amd engine: ") + rsasa_status_string(rc);
+    if (o.context) m += std::string(": ") + rsasa_context_last_error(o.context);
+    return m;
+}
+
+// Runs the GPU once for a set of prepared structures (those without a build error) and turns
+// the results into per-structure level outputs.  Build errors stay with their structure and do
+// not disturb the others (reference src/main.rs:446-454).
+template <typename Level>
+void run_batch(const OptionValues &o, const std::vector<const Structure *> &pdbs,
+               std::vector<Prepared> &prep, std::vector<Result<typename Level::Output>> &out)
+{
+    const size_t n_files = pdbs.size();
+    out.assign(n_files, Result<typename Level::Output>());
+    std::vector<uint32_t> s_off{0u}, seg_off{0u};
+    std::vector<size_t> members;
+    size_t n_total = 0;
+    for (size_t f = 0; f < n_files; f++) {
+        if (prep[f].err.error != SASACalcError::Ok) {
+            out[f].error = prep[f].err.error;
+            out[f].message = prep[f].err.message;
+            continue;
+        }
+        members.push_back(f);
+        for (uint32_t e : prep[f].seg_end) seg_off.push_back((uint32_t)n_total + e);
+        n_total += prep[f].atoms.size();
+        s_off.push_back((uint32_t)n_total);
     }
-    return r;
+    if (members.empty()) return;
+    std::vector<float> x(n_total), y(n_total), z(n_total), rad(n_total), atom(n_total, 0.f);
+    std::vector<std::uint64_t> id(n_total);
+    {
+        size_t i = 0;
+        for (size_t f : members)
+            for (const rsasa_atom_t &a : prep[f].atoms) {
+                x[i] = a.position[0]; y[i] = a.position[1]; z[i] = a.position[2];
+                rad[i] = a.radius; id[i] = a.id;
+                i++;
+            }
+    }
+    const size_t n_seg = seg_off.size() - 1;
+    std::vector<float> seg(n_seg, 0.f), global(members.size(), 0.f);
+    int rc = RSASA_OK;
+    if (n_total) {  // calculate_sasa_internal on an empty slice returns an empty Vec
+        rc = rsasa_calculate_sasa_batch(o.context, x.data(), y.data(), z.data(), rad.data(), id.data(),
+                                        s_off.data(), members.size(), o.probe_radius, o.n_points,
+                                        atom.data(), n_seg ? seg_off.data() : nullptr, n_seg,
+                                        n_seg ? seg.data() : nullptr);
+        if (rc == RSASA_OK && std::is_same<Level, ProteinLevel>::value)
+            rc = rsasa_segment_sums(o.context, atom.data(), n_total, s_off.data(), members.size(),
+                                    global.data());
+    }
+    size_t seg_pos = 0;
+    for (size_t m = 0; m < members.size(); m++) {
+        const size_t f = members[m];
+        if (rc != RSASA_OK) {
+            out[f].error = SASACalcError::Engine;
+            out[f].message = engine_message(o, rc);
+            continue;
+        }
+        out[f].value = finish<Level>(*pdbs[f], atom.data() + s_off[m], prep[f].atoms.size(),
+                                     seg.data() + seg_pos, global[m]);
+        seg_pos += prep[f].seg_end.size();
+    }
 }
 
 }  // namespace
@@ -516,125 +727,115 @@ Result<HotPathOut> run(const OptionValues &o, const std::vector<rsasa_atom_t> &a
 Result<std::vector<float>> run_hot_path(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms)
 {
     Result<std::vector<float>> out;
-    auto r = run(o, atoms, {});
-    out.error = r.error;
-    out.message = r.message;
-    out.value = std::move(r.value.atom);
+    out.value.assign(atoms.size(), 0.f);
+    if (atoms.empty()) return out;
+    const int rc = rsasa_calculate_sasa_internal(o.context, atoms.data(), atoms.size(),
+                                                 o.probe_radius, o.n_points, o.threads,
+                                                 out.value.data());
+    if (rc != RSASA_OK) {
+        out.error = SASACalcError::Engine;
+        out.message = engine_message(o, rc);
+    }
     return out;
 }
 
-// AtomLevel (options.rs:139-190)
-template <>
-struct Processor<AtomLevel> {
-    static Result<std::vector<float>> process(const Structure &pdb, const OptionValues &o)
-    {
-        std::vector<rsasa_atom_t> atoms;
-        BuildError err;
-        if (!select_atoms(pdb, o, true, atoms, err, [](size_t, size_t, size_t, size_t) {}))
-            return fail<std::vector<float>>(err);
-        return run_hot_path(o, atoms);  // process_atoms: atom_sasa.to_vec()
-    }
-};
+template <typename Level>
+std::vector<Result<typename Level::Output>> process_many(const std::vector<const Structure *> &pdbs,
+                                                         const OptionValues &o)
+{
+    std::vector<Prepared> prep(pdbs.size());
+    for (size_t f = 0; f < pdbs.size(); f++) prep[f] = prepare<Level>(*pdbs[f], o);
+    std::vector<Result<typename Level::Output>> out;
+    run_batch<Level>(o, pdbs, prep, out);
+    return out;
+}
 
-// ResidueLevel (options.rs:192-287)
-template <>
-struct Processor<ResidueLevel> {
-    static Result<std::vector<ResidueResult>> process(const Structure &pdb, const OptionValues &o)
-    {
-        std::vector<rsasa_atom_t> atoms;
-        std::vector<uint32_t> offs{0u};
-        BuildError err;
-        if (!select_atoms(pdb, o, true, atoms, err,
-                          [&](size_t, size_t, size_t, size_t end) { offs.push_back((uint32_t)end); }))
-            return fail<std::vector<ResidueResult>>(err);
-        Result<std::vector<ResidueResult>> out;
-        auto r = run(o, atoms, offs);
-        if (!r.ok()) { out.error = r.error; out.message = r.message; return out; }
-        size_t k = 0;
-        for (const Chain &chain : pdb.chains)
-            for (const Residue &res : chain.residues) {
-                std::string name;
-                res.name(&name);
-                out.value.push_back(ResidueResult{res.serial_number, res.insertion_code,
-                                                  r.value.segment[k++], name, is_polar_residue(name),
-                                                  chain.id});
-            }
-        return out;
-    }
-};
-
-// ChainLevel (options.rs:289-365), including the serialize_chain_id key: chains
-// whose ids serialise to the same number share the map entry of the LAST of them.
-template <>
-struct Processor<ChainLevel> {
-    static Result<std::vector<ChainResult>> process(const Structure &pdb, const OptionValues &o)
-    {
-        std::vector<rsasa_atom_t> atoms;
-        std::vector<uint32_t> chain_end(pdb.chains.size(), 0u);
-        BuildError err;
-        if (!select_atoms(pdb, o, true, atoms, err,
-                          [&](size_t ci, size_t, size_t, size_t end) { chain_end[ci] = (uint32_t)end; }))
-            return fail<std::vector<ChainResult>>(err);
-        // kept atoms of a chain are contiguous; a chain without residues owns an empty range
-        std::vector<uint32_t> offs{0u};
-        for (size_t ci = 0; ci < pdb.chains.size(); ci++)
-            offs.push_back(std::max(offs.back(), chain_end[ci]));
-        Result<std::vector<ChainResult>> out;
-        auto r = run(o, atoms, offs);
-        if (!r.ok()) { out.error = r.error; out.message = r.message; return out; }
-        std::map<std::int64_t, size_t> key_to_chain;  // parent_to_atoms.insert overwrites
-        for (size_t ci = 0; ci < pdb.chains.size(); ci++) key_to_chain[serialize_chain_id(pdb.chains[ci].id)] = ci;
-        for (const Chain &chain : pdb.chains)
-            out.value.push_back(ChainResult{chain.id, r.value.segment[key_to_chain[serialize_chain_id(chain.id)]]});
-        return out;
-    }
-};
-
-// ProteinLevel (options.rs:367-464): ids ignore the alt-loc (:453).
-template <>
-struct Processor<ProteinLevel> {
-    static Result<ProteinResult> process(const Structure &pdb, const OptionValues &o)
-    {
-        std::vector<rsasa_atom_t> atoms;
-        std::vector<uint32_t> offs{0u};
-        BuildError err;
-        if (!select_atoms(pdb, o, false, atoms, err,
-                          [&](size_t, size_t, size_t, size_t end) { offs.push_back((uint32_t)end); }))
-            return fail<ProteinResult>(err);
-        Result<ProteinResult> out;
-        auto r = run(o, atoms, offs);
-        if (!r.ok()) { out.error = r.error; out.message = r.message; return out; }
-        float polar = 0.f, non_polar = 0.f;  // options.rs:376-402
-        size_t k = 0;
-        for (const Chain &chain : pdb.chains)
-            for (const Residue &res : chain.residues) {
-                std::string name;
-                res.name(&name);
-                if (is_polar_residue(name)) polar += r.value.segment[k]; else non_polar += r.value.segment[k];
-                k++;
-            }
-        // global_total = simd_sum(atom_sasa) (options.rs:404): one sequential f32 sum over all atoms
-        float global = 0.f;
-        if (!atoms.empty()) {
-            const uint32_t all[2] = {0u, (uint32_t)atoms.size()};
-            const int rc = rsasa_segment_sums(o.context, r.value.atom.data(), atoms.size(), all, 1, &global);
-            if (rc != RSASA_OK) {
-                out.error = SASACalcError::Engine;
-                out.message = std::string("rustsasa_amd engine: ") + rsasa_status_string(rc);
-                return out;
-            }
+// Directory mode at library level (reference src/main.rs:342-480 without the CLI): files are
+// parsed and filtered on `host_threads` threads, then each chunk of `files_per_batch` structures
+// is ONE GPU batch.
+template <typename Level>
+std::vector<Result<typename Level::Output>> process_files(const std::vector<std::string> &paths,
+                                                          const OptionValues &o, unsigned host_threads,
+                                                          size_t files_per_batch, FilesTimings *timings)
+{
+    using Clock = std::chrono::steady_clock;
+    std::vector<Result<typename Level::Output>> all(paths.size());
+    if (host_threads == 0) host_threads = std::max(1u, std::thread::hardware_concurrency());
+    if (files_per_batch == 0) files_per_batch = 4096;
+    FilesTimings t{};
+    const auto t_begin = Clock::now();
+    for (size_t base = 0; base < paths.size(); base += files_per_batch) {
+        const size_t n = std::min(files_per_batch, paths.size() - base);
+        std::vector<Structure> pdbs(n);
+        std::vector<Prepared> prep(n);
+        std::vector<std::string> open_error(n);
+        const auto t0 = Clock::now();
+        {
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < n;) {
+                    try {
+                        pdbs[i] = Structure::open(paths[base + i]);
+                        prep[i] = prepare<Level>(pdbs[i], o);
+                    } catch (const std::exception &e) {
+                        open_error[i] = e.what();
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            const unsigned nt = (unsigned)std::min<size_t>(host_threads, n);
+            for (unsigned k = 1; k < nt; k++) pool.emplace_back(worker);
+            worker();
+            for (auto &th : pool) th.join();
         }
-        out.value = ProteinResult{global, polar, non_polar};
-        return out;
+        const auto t1 = Clock::now();
+        std::vector<const Structure *> ptrs(n);
+        for (size_t i = 0; i < n; i++) {
+            ptrs[i] = &pdbs[i];
+            if (!open_error[i].empty()) {  // unreadable file: report, keep going (main.rs:446-454)
+                prep[i].err = {SASACalcError::Engine, "cannot read structure: " + open_error[i]};
+            }
+            t.n_atoms += prep[i].atoms.size();
+        }
+        std::vector<Result<typename Level::Output>> out;
+        run_batch<Level>(o, ptrs, prep, out);
+        const auto t2 = Clock::now();
+        for (size_t i = 0; i < n; i++) all[base + i] = std::move(out[i]);
+        t.parse_seconds += std::chrono::duration<double>(t1 - t0).count();
+        t.compute_seconds += std::chrono::duration<double>(t2 - t1).count();
     }
-};
+    t.total_seconds = std::chrono::duration<double>(Clock::now() - t_begin).count();
+    t.n_files = paths.size();
+    if (timings) *timings = t;
+    return all;
+}
+
+#define RSASA_INSTANTIATE(L)                                                                          \
+    template std::vector<Result<L::Output>> process_many<L>(const std::vector<const Structure *> &,  \
+                                                            const OptionValues &);                   \
+    template std::vector<Result<L::Output>> process_files<L>(const std::vector<std::string> &,       \
+                                                             const OptionValues &, unsigned, size_t, \
+                                                             FilesTimings *);
+RSASA_INSTANTIATE(AtomLevel)
+RSASA_INSTANTIATE(ResidueLevel)
+RSASA_INSTANTIATE(ChainLevel)
+RSASA_INSTANTIATE(ProteinLevel)
+#undef RSASA_INSTANTIATE
 
 }  // namespace detail
 
 template <typename Level>
 Result<typename Level::Output> SASAOptions<Level>::process(const Structure &pdb) const
 {
-    return detail::Processor<Level>::process(pdb, o_);
+    return std::move(detail::process_many<Level>({&pdb}, o_)[0]);
+}
+
+template <typename Level>
+std::vector<Result<typename Level::Output>> SASAOptions<Level>::process_files(
+    const std::vector<std::string> &paths, unsigned host_threads, size_t files_per_batch,
+    FilesTimings *timings) const
+{
+    return detail::process_files<Level>(paths, o_, host_threads, files_per_batch, timings);
 }
 
 template class SASAOptions<AtomLevel>;

@@ -3,8 +3,12 @@
 // src/structures/atomic.rs:62-70 + src/utils/io.rs:11-13).  Not a port of the
 // reference CLI (src/main.rs), which is out of scope.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <iostream>
 #include <string>
+#include <vector>
 
 #include "../../../include/rustsasa_amd.hpp"
 
@@ -46,8 +50,85 @@ static int fail(const Result<T> &r)
     return 2;
 }
 
+// `files <level> <list file>`: directory mode at library level (SASAOptions::process_files).
+template <typename L, typename PrintOne>
+static int run_files(int argc, char **argv, PrintOne print_one)
+{
+    std::vector<std::string> paths;
+    {
+        std::ifstream f(argv[3]);
+        for (std::string line; std::getline(f, line);)
+            if (!line.empty()) paths.push_back(line);
+    }
+    unsigned threads = 0;
+    size_t batch = 0;
+    bool full = false;
+    for (int i = 4; i < argc; i++) {
+        if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (size_t)std::atol(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--full")) full = true;
+    }
+    FilesTimings t;
+    auto res = make<L>(argc - 1, argv + 1).process_files(paths, threads, batch, &t);
+    size_t n_ok = 0;
+    for (const auto &r : res) n_ok += r.ok();
+    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"results\":[",
+                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds);
+    for (size_t i = 0; i < res.size(); i++) {
+        std::printf("%s", i ? "," : "");
+        if (!res[i].ok()) {
+            std::printf("{\"error\":%d}", (int)res[i].error);
+        } else if (full) {
+            print_one(res[i].value);
+        } else {
+            std::printf("{}");
+        }
+    }
+    std::printf("]}\n");
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && std::string(argv[1]) == "decimal") {
+        // reader self-check: for every stdin token print the fast parser's and strtod's bits
+        for (std::string tok; std::cin >> tok;) {
+            const double a = parse_decimal_text(tok), b = std::strtod(tok.c_str(), nullptr);
+            std::printf("%a %a\n", a, b);
+        }
+        return 0;
+    }
+    if (argc >= 4 && std::string(argv[1]) == "files") {
+        const std::string level = argv[2];
+        try {
+            if (level == "atom")
+                return run_files<AtomLevel>(argc, argv, [](const std::vector<float> &v) {
+                    std::printf("[");
+                    for (size_t i = 0; i < v.size(); i++) std::printf("%s%.9g", i ? "," : "", v[i]);
+                    std::printf("]");
+                });
+            if (level == "residue")
+                return run_files<ResidueLevel>(argc, argv, [](const std::vector<ResidueResult> &v) {
+                    std::printf("[");
+                    for (size_t i = 0; i < v.size(); i++) std::printf("%s%.9g", i ? "," : "", v[i].value);
+                    std::printf("]");
+                });
+            if (level == "chain")
+                return run_files<ChainLevel>(argc, argv, [](const std::vector<ChainResult> &v) {
+                    std::printf("[");
+                    for (size_t i = 0; i < v.size(); i++) std::printf("%s%.9g", i ? "," : "", v[i].value);
+                    std::printf("]");
+                });
+            if (level == "protein")
+                return run_files<ProteinLevel>(argc, argv, [](const ProteinResult &v) {
+                    std::printf("[%.9g,%.9g,%.9g]", v.global_total, v.polar_total, v.non_polar_total);
+                });
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return 70;
+        }
+        return 64;
+    }
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s <atom|residue|chain|protein> <file> [options]\n", argv[0]);
         return 64;

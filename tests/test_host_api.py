@@ -165,3 +165,106 @@ def test_options_hetatms_with_vdw_fallback_and_points():
     atom, _, _ = expected("2drt.pdb", n_points=200, include_hetatms=True, vdw_fallback=True)
     got = run_cli("atom", "2drt.pdb", "--include-hetatms", "--allow-vdw-fallback", "--n-points", "200")["Atom"]
     assert np.array_equal(np.array(got, np.float32), atom)
+
+
+# ---- the reader's decimal parser and directory mode (process_files) ------------------
+
+def test_decimal_parser_equals_strtod():
+    rng = np.random.default_rng(1)
+    toks = []
+    for _ in range(4000):
+        toks.append("%8.3f" % rng.uniform(-999, 9999))                       # PDB coordinate field
+        toks.append(repr(round(float(rng.normal(scale=10.0 ** int(rng.integers(-3, 6)))), int(rng.integers(0, 9)))))
+        toks.append("%d" % rng.integers(-10 ** 9, 10 ** 9))
+        toks.append("%.*f" % (int(rng.integers(0, 18)), rng.uniform(-1e4, 1e4)))  # long mantissas
+        toks.append("%.6e" % rng.normal(scale=1e3))                          # exponents -> strtod path
+    toks += ["0", "-0.0", ".5", "5.", "+3.25", "00012.500", "1e400", "abc", "1.2.3"]
+    p = subprocess.run([CLI, "decimal"], input=" ".join(t.strip() for t in toks), capture_output=True,
+                       text=True)
+    assert p.returncode == 0
+    lines = p.stdout.strip().split("\n")
+    assert len(lines) == len(toks)
+    bad = [(t, l) for t, l in zip(toks, lines) if l.split()[0] != l.split()[1]]
+    assert not bad, bad[:5]
+
+
+def _write_variant(src, dst, rng):
+    """Rigidly moved copy of a PDB fixture (columns 31-54 rewritten)."""
+    import bench_workloads as bw
+    rot = bw._random_rotation(rng)
+    shift = rng.uniform(-30, 30, size=3)
+    lines = open(sio.data_path(src)).read().split("\n")
+    pts = np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in lines
+                    if l.startswith(("ATOM  ", "HETATM"))])
+    c = pts.mean(axis=0)
+    with open(dst, "w") as f:
+        for l in lines:
+            if l.startswith(("ATOM  ", "HETATM")):
+                v = (np.array([float(l[30:38]), float(l[38:46]), float(l[46:54])]) - c) @ rot.T + shift
+                l = l[:30] + "%8.3f%8.3f%8.3f" % tuple(v) + l[54:]
+            f.write(l + "\n")
+
+
+def _make_file_set(tmp_path, n=12):
+    rng = np.random.default_rng(9)
+    paths = []
+    for i in range(n):
+        src = ["1jcd.pdb", "151L_H3.pdb", "bad_seqadv_1A06.pdb", "2drt.pdb"][i % 4]
+        dst = str(tmp_path / f"v{i:03d}_{src}")
+        _write_variant(src, dst, rng)
+        paths.append(dst)
+    paths.insert(3, sio.data_path("example.cif"))
+    paths.insert(5, str(tmp_path / "does_not_exist.pdb"))
+    # a structure whose radius lookup fails (unknown residue name) must only fail itself
+    broken = str(tmp_path / "unknown_residue.pdb")
+    with open(broken, "w") as f:
+        f.write("ATOM      1  N   XYZ A   1      11.104   6.134  -6.504  1.00  0.00           N  \n")
+    paths.insert(8, broken)
+    lst = str(tmp_path / "files.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    return paths, lst
+
+
+def test_process_files_reports_errors_per_file(tmp_path):
+    paths, lst = _make_file_set(tmp_path, 4)
+    p = subprocess.run([CLI, "files", "residue", lst, "--threads", "3"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:500]
+    got = json.loads(p.stdout)
+    assert got["n_files"] == len(paths)
+    errs = {i: r.get("error") for i, r in enumerate(got["results"]) if "error" in r}
+    i_missing = next(i for i, p_ in enumerate(paths) if p_.endswith("does_not_exist.pdb"))
+    i_broken = next(i for i, p_ in enumerate(paths) if p_.endswith("unknown_residue.pdb"))
+    assert errs[i_missing] == 7 and errs[i_broken] == 3   # unreadable file / RadiusMissing
+    import rustsasa_amd
+    if rustsasa_amd.device_count() == 0:            # no GPU: the good files fail loudly too
+        assert got["n_ok"] == 0 and all(r.get("error") == 7 for i, r in enumerate(got["results"])
+                                        if i not in (i_missing, i_broken))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [0, 5])
+def test_process_files_matches_oracle(tmp_path, batch):
+    paths, lst = _make_file_set(tmp_path, 12)
+    p = subprocess.run([CLI, "files", "residue", lst, "--threads", "4", "--batch", str(batch), "--full"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:500]
+    got = json.loads(p.stdout)
+    assert got["n_ok"] == len(paths) - 2
+    for i, (path, r) in enumerate(zip(paths, got["results"])):
+        if path.endswith(("does_not_exist.pdb", "unknown_residue.pdb")):
+            assert "error" in r
+            continue
+        # `expected` resolves names under tests/golden/data; give it the absolute path instead
+        atoms_backup = sio.data_path
+        try:
+            sio.data_path = lambda name, _p=path: _p if name == "__file__" else atoms_backup(name)
+            _, res, _ = expected("__file__")
+        finally:
+            sio.data_path = atoms_backup
+        assert np.array_equal(np.array(r, np.float32), res), path
+    # protein level through the same batch path
+    p = subprocess.run([CLI, "files", "protein", lst, "--full"], capture_output=True, text=True)
+    prot = json.loads(p.stdout)["results"]
+    single = run_cli("protein", "example.cif")["Protein"]
+    i_cif = paths.index(sio.data_path("example.cif"))
+    assert prot[i_cif] == [single["global_total"], single["polar_total"], single["non_polar_total"]]
