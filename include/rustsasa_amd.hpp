@@ -184,7 +184,7 @@ public:
     Result<typename Level::Output> process(const Structure &pdb) const;
 
     // Directory mode at library level (reference src/main.rs:342-480, `files.par_iter()` :375):
-    // parse + select on `host_threads` threads (0 = all), then ONE GPU batch per
+    // parse + select on `host_threads` threads (0 = min(16, all)), then ONE GPU batch per
     // `files_per_batch` structures (0 = 4096).  A file that fails (unreadable, missing radius,
     // ...) gets its own error; the others are unaffected (main.rs:446-454).
     std::vector<Result<typename Level::Output>> process_files(const std::vector<std::string> &paths,

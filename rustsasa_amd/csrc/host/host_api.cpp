@@ -661,12 +661,32 @@ std::string engine_message(const OptionValues &o, int rc)
     return m;
 }
 
+// Static-chunked parallel loop over [0, n) on up to `threads` std::threads (host glue only).
+template <typename F>
+void parallel_for(size_t n, unsigned threads, F body)
+{
+    const unsigned nt = (unsigned)std::min<size_t>(std::max(1u, threads), n);
+    if (nt <= 1) {
+        for (size_t i = 0; i < n; i++) body(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (size_t i; (i = next.fetch_add(1)) < n;) body(i);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned k = 1; k < nt; k++) pool.emplace_back(worker);
+    worker();
+    for (auto &th : pool) th.join();
+}
+
 // Runs the GPU once for a set of prepared structures (those without a build error) and turns
 // the results into per-structure level outputs.  Build errors stay with their structure and do
 // not disturb the others (reference src/main.rs:446-454).
 template <typename Level>
 void run_batch(const OptionValues &o, const std::vector<const Structure *> &pdbs,
-               std::vector<Prepared> &prep, std::vector<Result<typename Level::Output>> &out)
+               std::vector<Prepared> &prep, std::vector<Result<typename Level::Output>> &out,
+               unsigned host_threads = 1)
 {
     const size_t n_files = pdbs.size();
     out.assign(n_files, Result<typename Level::Output>());
@@ -687,15 +707,14 @@ void run_batch(const OptionValues &o, const std::vector<const Structure *> &pdbs
     if (members.empty()) return;
     std::vector<float> x(n_total), y(n_total), z(n_total), rad(n_total), atom(n_total, 0.f);
     std::vector<std::uint64_t> id(n_total);
-    {
-        size_t i = 0;
-        for (size_t f : members)
-            for (const rsasa_atom_t &a : prep[f].atoms) {
-                x[i] = a.position[0]; y[i] = a.position[1]; z[i] = a.position[2];
-                rad[i] = a.radius; id[i] = a.id;
-                i++;
-            }
-    }
+    parallel_for(members.size(), host_threads, [&](size_t m) {
+        size_t i = s_off[m];
+        for (const rsasa_atom_t &a : prep[members[m]].atoms) {
+            x[i] = a.position[0]; y[i] = a.position[1]; z[i] = a.position[2];
+            rad[i] = a.radius; id[i] = a.id;
+            i++;
+        }
+    });
     const size_t n_seg = seg_off.size() - 1;
     std::vector<float> seg(n_seg, 0.f), global(members.size(), 0.f);
     int rc = RSASA_OK;
@@ -708,18 +727,19 @@ void run_batch(const OptionValues &o, const std::vector<const Structure *> &pdbs
             rc = rsasa_segment_sums(o.context, atom.data(), n_total, s_off.data(), members.size(),
                                     global.data());
     }
-    size_t seg_pos = 0;
-    for (size_t m = 0; m < members.size(); m++) {
+    std::vector<size_t> seg_pos(members.size() + 1, 0);
+    for (size_t m = 0; m < members.size(); m++) seg_pos[m + 1] = seg_pos[m] + prep[members[m]].seg_end.size();
+    const std::string engine_err = rc != RSASA_OK ? engine_message(o, rc) : std::string();
+    parallel_for(members.size(), host_threads, [&](size_t m) {
         const size_t f = members[m];
         if (rc != RSASA_OK) {
             out[f].error = SASACalcError::Engine;
-            out[f].message = engine_message(o, rc);
-            continue;
+            out[f].message = engine_err;
+            return;
         }
         out[f].value = finish<Level>(*pdbs[f], atom.data() + s_off[m], prep[f].atoms.size(),
-                                     seg.data() + seg_pos, global[m]);
-        seg_pos += prep[f].seg_end.size();
-    }
+                                     seg.data() + seg_pos[m], global[m]);
+    });
 }
 
 }  // namespace
@@ -760,7 +780,9 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
 {
     using Clock = std::chrono::steady_clock;
     std::vector<Result<typename Level::Output>> all(paths.size());
-    if (host_threads == 0) host_threads = std::max(1u, std::thread::hardware_concurrency());
+    // parsing is allocation heavy and stops scaling early (measured: 8-16 threads on a
+    // 256-thread host), so the default is capped
+    if (host_threads == 0) host_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (files_per_batch == 0) files_per_batch = 4096;
     FilesTimings t{};
     const auto t_begin = Clock::now();
@@ -770,24 +792,14 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
         std::vector<Prepared> prep(n);
         std::vector<std::string> open_error(n);
         const auto t0 = Clock::now();
-        {
-            std::atomic<size_t> next{0};
-            auto worker = [&]() {
-                for (size_t i; (i = next.fetch_add(1)) < n;) {
-                    try {
-                        pdbs[i] = Structure::open(paths[base + i]);
-                        prep[i] = prepare<Level>(pdbs[i], o);
-                    } catch (const std::exception &e) {
-                        open_error[i] = e.what();
-                    }
-                }
-            };
-            std::vector<std::thread> pool;
-            const unsigned nt = (unsigned)std::min<size_t>(host_threads, n);
-            for (unsigned k = 1; k < nt; k++) pool.emplace_back(worker);
-            worker();
-            for (auto &th : pool) th.join();
-        }
+        parallel_for(n, host_threads, [&](size_t i) {
+            try {
+                pdbs[i] = Structure::open(paths[base + i]);
+                prep[i] = prepare<Level>(pdbs[i], o);
+            } catch (const std::exception &e) {
+                open_error[i] = e.what();
+            }
+        });
         const auto t1 = Clock::now();
         std::vector<const Structure *> ptrs(n);
         for (size_t i = 0; i < n; i++) {
@@ -798,7 +810,7 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
             t.n_atoms += prep[i].atoms.size();
         }
         std::vector<Result<typename Level::Output>> out;
-        run_batch<Level>(o, ptrs, prep, out);
+        run_batch<Level>(o, ptrs, prep, out, host_threads);
         const auto t2 = Clock::now();
         for (size_t i = 0; i < n; i++) all[base + i] = std::move(out[i]);
         t.parse_seconds += std::chrono::duration<double>(t1 - t0).count();

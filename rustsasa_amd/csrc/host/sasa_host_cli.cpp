@@ -2,6 +2,7 @@
 // prints the level result as JSON (shape of the reference's SASAResult serialisation,
 // src/structures/atomic.rs:62-70 + src/utils/io.rs:11-13).  Not a port of the
 // reference CLI (src/main.rs), which is out of scope.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -96,6 +97,17 @@ int main(int argc, char **argv)
             const double a = parse_decimal_text(tok), b = std::strtod(tok.c_str(), nullptr);
             std::printf("%a %a\n", a, b);
         }
+        return 0;
+    }
+    if (argc >= 4 && std::string(argv[1]) == "parse-bench") {
+        // reader micro-benchmark: open + parse the file `reps` times on one thread
+        const int reps = std::atoi(argv[3]);
+        size_t atoms = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; i++) atoms += Structure::open(argv[2]).atom_count();
+        const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("{\"reps\":%d,\"atoms\":%zu,\"ms_per_file\":%.4f,\"ns_per_atom\":%.1f}\n", reps,
+                    atoms / (size_t)reps, s / reps * 1e3, s / (double)atoms * 1e9);
         return 0;
     }
     if (argc >= 4 && std::string(argv[1]) == "files") {

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""End-to-end directory-mode measurement (files -> per-residue SASA), C++ host API.
+
+Writes N synthetic AF-proteome-like PDB files (residue-aligned fragments of the fixture
+proteins, rigidly moved; same size distribution as bench_workloads.synthetic_proteome) to a
+scratch directory, then runs `sasa_host_cli files residue` (SASAOptions::process_files):
+multi-threaded parse + atom selection on the host, one GPU batch per chunk of files.
+Reports files/s with the parse / compute split.  This is the parse- and PCIe-inclusive
+number; bench.py's `value` is the HBM-resident hot path only.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import bench_workloads as bw  # noqa: E402
+import structio as sio  # noqa: E402
+
+CLI = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
+
+
+def load_domains():
+    doms = []
+    for name in bw.FIXTURES:
+        recs = [a for a in sio.read_structure(sio.data_path(name)) if not a.hetero and a.element != "H"]
+        xyz = np.array([[a.x, a.y, a.z] for a in recs])
+        keys = [(a.chain, a.resseq, a.icode) for a in recs]
+        starts = [0] + [i for i in range(1, len(keys)) if keys[i] != keys[i - 1]] + [len(keys)]
+        doms.append((recs, xyz - xyz.mean(axis=0), np.array(starts)))
+    return doms
+
+
+def write_structure(path, n_target, rng, doms):
+    lines, n, serial, resno, slot = [], 0, 1, 1, 0
+    while n < n_target:
+        recs, xyz, starts = doms[rng.integers(len(doms))]
+        want = n_target - n
+        n_res = len(starts) - 1
+        if want >= starts[-1]:
+            r0 = 0
+        else:
+            last = int(np.searchsorted(starts, starts[-1] - want, side="right") - 1)
+            r0 = int(rng.integers(max(last, 0) + 1))
+        r1 = min(max(int(np.searchsorted(starts, starts[r0] + want, side="right") - 1), r0 + 1), n_res)
+        a0, a1 = starts[r0], starts[r1]
+        frag = xyz[a0:a1] - xyz[a0:a1].mean(axis=0)
+        frag = frag @ bw._random_rotation(rng).T + rng.normal(scale=0.05, size=frag.shape)
+        frag = frag + np.array([slot % 4, (slot // 4) % 4, slot // 16]) * 90.0
+        slot += 1
+        chain = "ABCDEFGHIJKLMNOPQRSTUVWXYZ"[slot % 26]
+        prev_key = None
+        for k in range(a0, a1):
+            a = recs[k]
+            key = (a.chain, a.resseq, a.icode)
+            if key != prev_key and prev_key is not None:
+                resno += 1
+            prev_key = key
+            x, y, z = frag[k - a0]
+            name = a.name if len(a.name) == 4 else " " + a.name
+            lines.append("ATOM  %5d %-4s %3s %1s%4d    %8.3f%8.3f%8.3f  1.00  0.00          %2s  " %
+                         (serial % 100000, name, a.resname, chain, resno % 10000, x, y, z, a.element))
+            serial += 1
+        resno += 1
+        n += a1 - a0
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\nEND\n")
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--files", type=int, default=1500)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--dir", default=None)
+    ap.add_argument("--repeat", type=int, default=3)
+    args = ap.parse_args()
+    d = args.dir or tempfile.mkdtemp(prefix="rsasa_files_")
+    rng = np.random.default_rng(bw.PROTEOME_SEED)
+    sizes = np.clip(rng.lognormal(np.log(2000.0), 0.75, args.files), 150, 25000).astype(int)
+    doms = load_domains()
+    t0 = time.time()
+    paths, atoms = [], 0
+    for i, n_t in enumerate(sizes):
+        p = os.path.join(d, f"s{i:05d}.pdb")
+        atoms += write_structure(p, int(n_t), rng, doms)
+        paths.append(p)
+    lst = os.path.join(d, "files.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    gen_s = time.time() - t0
+    best = None
+    for _ in range(args.repeat):
+        cmd = [CLI, "files", "residue", lst, "--threads", str(args.threads), "--batch", str(args.batch)]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-500:]
+        r = json.loads(p.stdout)
+        r.pop("results")
+        if best is None or r["total_s"] < best["total_s"]:
+            best = r
+    best.update({"files_per_s": round(best["n_files"] / best["total_s"], 1),
+                 "atoms_per_file": round(atoms / args.files, 1), "generation_s": round(gen_s, 1),
+                 "host_threads": args.threads or os.cpu_count(),
+                 "bytes_on_disk": sum(os.path.getsize(p) for p in paths)})
+    print(json.dumps(best))
+
+
+if __name__ == "__main__":
+    main()
