@@ -154,6 +154,7 @@ def main():
     for _ in range(args.steps):
         step()
         t = ctx.timings()
+        n_cells = int(t["n_cells"])
         occl_ms.append(t["occlusion_ms"])
         grid_ms.append(t["grid_build_ms"])
         agg_ms.append(t["aggregate_ms"])
@@ -191,6 +192,7 @@ def main():
             "config": {"workload": name, "structures_per_gpu": batch.n_structures,
                        "atoms_per_gpu": batch.n_atoms, "residues_per_gpu": batch.n_residues,
                        "candidates_per_atom": round(k_sum / max(batch.n_atoms, 1), 2),
+                       "grid_cells_per_gpu": n_cells,
                        "atoms_per_s": round(total_atoms * args.steps / elapsed, 1),
                        "ids": not args.no_ids, "parallelism": f"{world} x independent shards"},
             "roofline": {"bound": "hbm", "kernel": "k_occlusion", "achieved": round(achieved, 2),

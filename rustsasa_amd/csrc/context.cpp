@@ -219,7 +219,7 @@ int enqueue_pending(rsasa_context *ctx)
     }
 
     if (ctx->cell_capacity == 0)
-        ctx->cell_capacity = std::max<uint64_t>(1u << 16, 12ull * N + 64ull * S);
+        ctx->cell_capacity = std::max<uint64_t>(1u << 16, 20ull * N + 512ull * S);
     ctx->cell_capacity = std::min<uint64_t>(ctx->cell_capacity, 0xFFFFFFF0ull);
 
     const bool has_id = bt.id != nullptr;
