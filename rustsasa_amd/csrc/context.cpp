@@ -399,6 +399,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     std::memset(ctx->h_status, 0, sizeof(BatchStatus));
     if (const char *v = std::getenv("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
     if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
+    if (const char *v = std::getenv("RSASA_DEBUG_STOP")) ctx->tuning.debug_stop = (uint32_t)std::atoi(v);
     *out_ctx = ctx;
     return RSASA_OK;
 }

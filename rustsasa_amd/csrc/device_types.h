@@ -85,6 +85,7 @@ struct BatchView {
 struct OcclusionTuning {
     int kernel_version = 3;       // 0 = all-pairs kernel, 2 = tiled two-phase, 3 = tiled two-phase, lean
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
+    uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
 };
 
 // Launchers implemented in kernels.hip / occlusion.hip.  Each only enqueues on `stream`.

@@ -34,6 +34,7 @@ struct OccArgs {
     Lattice lat;
     uint32_t n_blocks;        // launched workgroups (for the XCD swizzle)
     uint32_t atoms_per_wave;  // consecutive cell-sorted atoms handled by one wave
+    uint32_t debug_stop;      // timing ablation (v3 only)
 };
 
 #include "occlusion_v0.inc"
@@ -415,7 +416,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
                       hipStream_t stream)
 {
     if (!b.n_atoms) return;
-    OccArgs a{b, lat, 0, 1};
+    OccArgs a{b, lat, 0, 1, tune.debug_stop};
     if (tune.kernel_version == 0) {
         a.atoms_per_wave = 1;
     } else if (tune.atoms_per_wave > 0) {
@@ -425,6 +426,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         const uint32_t waves_full = 256u * 4u * 8u * 4u;
         a.atoms_per_wave = max(1u, min(16u, b.n_atoms / waves_full));
     }
+    if (tune.kernel_version == 3) a.atoms_per_wave = min(a.atoms_per_wave, (uint32_t)kMaxAtomsPerWave);
     a.n_blocks = cdiv(cdiv(b.n_atoms, a.atoms_per_wave), 4);
     const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
     // v3 walks the chunk groups inside one sweep, two chunks at a time, for any n_points
