@@ -430,7 +430,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     a.n_blocks = cdiv(cdiv(b.n_atoms, a.atoms_per_wave), 4);
     const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
     // v3 walks the chunk groups inside one sweep, two chunks at a time, for any n_points
-    if (n_chunks <= 2 || tune.kernel_version == 3) launch_occ<2>(a, tune.kernel_version, stream);
+    if (n_chunks <= 2 || tune.kernel_version >= 3) launch_occ<2>(a, tune.kernel_version, stream);
     else if (n_chunks <= 4) launch_occ<4>(a, tune.kernel_version, stream);
     else launch_occ<16>(a, tune.kernel_version, stream);
 }
