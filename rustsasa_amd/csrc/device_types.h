@@ -83,7 +83,7 @@ struct BatchView {
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
-    int kernel_version = 3;       // 0 = all-pairs kernel, 2 = tiled two-phase, 3 = tiled two-phase, lean
+    int kernel_version = 3;       // 0 = all-pairs reference kernel, 3 = culled sweep + two-phase point tests
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
     uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
 };
