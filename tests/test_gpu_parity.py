@@ -328,3 +328,60 @@ def test_kernel_variants_agree(env, monkeypatch):
     assert np.array_equal(k[:len(k_ref)], k_ref)
     assert np.array_equal(atom960, po.calculate_sasa_internal(b.x[:3000], b.y[:3000], b.z[:3000],
                                                               b.radius[:3000], b.ids[:3000], PROBE, 960, 8))
+
+
+# ---- size-independent properties ----------------------------------------------------
+
+def test_permutation_invariance(ctx):
+    """A per-atom value depends on the SET of atoms, not on their order in the input: shuffling
+    the atoms permutes the output bit for bit (the candidate set and every test are order free)."""
+    xyz, r, _, ids = bw.fixture_soa("bad_seqadv_1A06.pdb")
+    x, y, z = (np.ascontiguousarray(xyz[:, k]).astype(np.float32) for k in range(3))
+    base = ctx.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100)
+    rng = np.random.default_rng(4)
+    for _ in range(3):
+        perm = rng.permutation(len(x))
+        got = ctx.calculate_sasa_soa(x[perm].copy(), y[perm].copy(), z[perm].copy(), r[perm].copy(),
+                                     ids[perm].copy(), PROBE, 100)
+        assert np.array_equal(got, base[perm])
+
+
+def test_batch_neighbours_do_not_interact(ctx):
+    """Structures of a batch are independent even when they overlap in space."""
+    xyz, r, _, ids = bw.fixture_soa("1jcd.pdb")
+    x, y, z = (np.ascontiguousarray(xyz[:, k]).astype(np.float32) for k in range(3))
+    one = ctx.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100)
+    reps = 5
+    so = np.arange(0, (reps + 1) * len(x), len(x), dtype=np.uint32)
+    atom, _ = ctx.calculate_sasa_batch(np.tile(x, reps), np.tile(y, reps), np.tile(z, reps),
+                                       np.tile(r, reps), np.tile(ids, reps), so, PROBE, 100)
+    assert np.array_equal(atom, np.tile(one, reps))
+
+
+def test_coincident_and_far_atoms(ctx):
+    """Coincident atoms (distance 0), atoms exactly at the search radius and a sparse 2 km box."""
+    r0 = np.float32(1.8)
+    sr = np.float32(np.float32(r0 + r0) + np.float32(2.8))      # r_i + max_r + 2p
+    c = np.array([[0, 0, 0], [0, 0, 0], [float(sr), 0, 0], [0, float(sr) + 1e-3, 0],
+                  [2e3, 2e3, 2e3], [2e3 + 1.5, 2e3, 2e3]], np.float32)  # 625^3 cells
+    r = np.full(len(c), r0, np.float32)
+    ids = np.arange(len(c), dtype=np.uint64)
+    got = ctx.calculate_sasa_soa(c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy(), r, ids, PROBE, 100)
+    want = po.calculate_sasa_internal(c[:, 0], c[:, 1], c[:, 2], r, ids, PROBE, 100, 8)
+    assert np.array_equal(got, want)
+
+
+def test_hypothesis_random_clouds(ctx):
+    """Random point clouds over a range of densities, radii and probes (seeded; oracle compared)."""
+    rng = np.random.default_rng(123)
+    for trial in range(12):
+        n = int(rng.integers(1, 400))
+        box = float(rng.uniform(4.0, 40.0))
+        c = rng.uniform(0, box, size=(n, 3)).astype(np.float32)
+        r = rng.uniform(0.8, 2.4, size=n).astype(np.float32)
+        ids = rng.integers(0, max(2, n // 2 if trial % 3 == 0 else 10 * n), size=n).astype(np.uint64)
+        probe = float(rng.choice([0.0, 0.7, 1.4, 2.0]))
+        n_points = int(rng.choice([17, 64, 100, 333]))
+        got = ctx.calculate_sasa_soa(c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy(), r, ids, probe, n_points)
+        want = po.calculate_sasa_internal(c[:, 0], c[:, 1], c[:, 2], r, ids, probe, n_points, 8)
+        assert np.array_equal(got, want), (trial, n, box, probe, n_points)
