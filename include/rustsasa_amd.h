@@ -136,6 +136,20 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
                         float probe_radius, size_t n_points, void *hip_stream);
 int rsasa_batch_wait(rsasa_context_t *ctx);
 
+/* MD-trajectory mode (the reference ecosystem's second workload: per-frame SASA of one
+ * topology, README.md:98-149 / paper.md:45): n_frames frames of the same n_atoms atoms.
+ * `xyz` is frame-major [n_frames][n_atoms][3] (HOST); radius / id / residue_offsets
+ * ([n_residues + 1], offsets within one frame) are given once.  Every frame is an
+ * independent structure (own bounding box, grid, max radius), exactly as n_frames separate
+ * calculate_sasa_internal calls (src/lib.rs:249-254).  out_atom_sasa is [n_frames][n_atoms],
+ * out_residue_sasa [n_frames][n_residues]; either may be NULL.  Only 12 bytes per atom and
+ * frame cross PCIe. */
+int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size_t n_frames,
+                                    size_t n_atoms, const float *radius, const uint64_t *id,
+                                    float probe_radius, size_t n_points, float *out_atom_sasa,
+                                    const uint32_t *residue_offsets, size_t n_residues,
+                                    float *out_residue_sasa);
+
 /* Strictly sequential f32 sums of contiguous segments of a host array, computed
  * on the GPU: out[k] = ((values[o[k]] + values[o[k]+1]) + ...) over
  * [offsets[k], offsets[k+1]).  This is the reference's simd_sum

@@ -67,6 +67,10 @@ struct Structure {
     static Structure from_pdb_text(const std::string &text);
     static Structure from_mmcif_text(const std::string &text);
     std::size_t atom_count() const;
+    // PDB text of the model (ATOM / HETATM records, b-factors included), e.g. after
+    // sasa_result_to_protein_object; save_pdb throws std::runtime_error on I/O failure.
+    std::string to_pdb_text() const;
+    void save_pdb(const std::string &path) const;
 };
 
 // ---- radii -------------------------------------------------------------------
@@ -200,6 +204,20 @@ extern template class SASAOptions<AtomLevel>;
 extern template class SASAOptions<ResidueLevel>;
 extern template class SASAOptions<ChainLevel>;
 extern template class SASAOptions<ProteinLevel>;
+
+// ---- output (reference src/utils/io.rs) -------------------------------------------
+// JSON in the shape serde gives the externally tagged SASAResult enum (io.rs:11-13,
+// atomic.rs:62-70): {"Atom":[..]}, {"Residue":[{..}]}, {"Chain":[{..}]}, {"Protein":{..}}.
+std::string sasa_result_to_json(const std::vector<float> &atom_level);
+std::string sasa_result_to_json(const std::vector<ResidueResult> &residue_level);
+std::string sasa_result_to_json(const std::vector<ChainResult> &chain_level);
+std::string sasa_result_to_json(const ProteinResult &protein_level);
+// Writes the values into the b-factors of `pdb` (io.rs:20-64).  Returns false with a message
+// where the reference would panic (result / structure size mismatch).
+bool sasa_result_to_protein_object(Structure &pdb, const std::vector<float> &atom_level, std::string *err);
+bool sasa_result_to_protein_object(Structure &pdb, const std::vector<ResidueResult> &residue_level, std::string *err);
+bool sasa_result_to_protein_object(Structure &pdb, const std::vector<ChainResult> &chain_level, std::string *err);
+bool sasa_result_to_protein_object(Structure &pdb, const ProteinResult &protein_level, std::string *err);
 
 // The reader's decimal parser (exact: equals strtod on every input); exposed for tests.
 double parse_decimal_text(const std::string &text);

@@ -73,6 +73,8 @@ SYMBOLS = {
                                            C.c_size_t, _vp]),
     "rsasa_calculate_sasa_batch": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t,
                                              C.c_float, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "rsasa_calculate_sasa_trajectory": (C.c_int, [_vp, _vp, C.c_size_t, C.c_size_t, _vp, _vp, C.c_float,
+                                                  C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
     "rsasa_segment_sums": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "rsasa_batch_enqueue": (C.c_int, [_vp, C.POINTER(DeviceBatch), C.c_float, C.c_size_t, _vp]),
     "rsasa_batch_wait": (C.c_int, [_vp]),

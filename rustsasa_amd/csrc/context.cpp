@@ -81,6 +81,7 @@ struct rsasa_context {
         sorted_orig, sorted_id, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
+    DeviceBuffer tr_xyz, tr_r, tr_id, tr_res;  // trajectory staging (frame-major xyz, per-topology columns)
     // pinned host
     Segment *h_segments = nullptr;
     size_t h_segments_cap = 0;
@@ -413,7 +414,8 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
-                            &ctx->in_res, &ctx->out_res, &ctx->out_k})
+                            &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->tr_xyz, &ctx->tr_r,
+                            &ctx->tr_id, &ctx->tr_res})
         release(*b);
     for (auto &kv : ctx->lattices)
         if (kv.second.d) (void)hipFree(kv.second.d);
@@ -635,6 +637,90 @@ int rsasa_calculate_sasa_internal(rsasa_context_t *ctx, const rsasa_atom_t *atom
     }
     return rsasa_calculate_sasa_soa(ctx, x, y, z, r, ids.data(), n_atoms, probe_radius, n_points,
                                     out_sasa);
+}
+
+int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size_t n_frames,
+                                    size_t n_atoms, const float *radius, const uint64_t *id,
+                                    float probe_radius, size_t n_points, float *out_atom_sasa,
+                                    const uint32_t *residue_offsets, size_t n_residues,
+                                    float *out_residue_sasa)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    const bool want_res = residue_offsets && n_residues;
+    if (n_frames == 0 || n_atoms == 0) return RSASA_OK;
+    if (!xyz || !radius) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "xyz / radius are NULL");
+    if (want_res && !out_residue_sasa) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "out_residue_sasa is NULL");
+    if (!out_atom_sasa && !want_res) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "no output requested");
+    if (n_atoms >= 0xFFFFFFF0ull || n_frames >= 0xFFFFFFF0ull || n_residues >= 0xFFFFFFF0ull)
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "trajectory too large for 32-bit indices");
+    if (want_res) {
+        if (residue_offsets[n_residues] > n_atoms)
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets exceed n_atoms");
+        for (size_t k = 0; k < n_residues; k++)
+            if (residue_offsets[k] > residue_offsets[k + 1])
+                return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets must be non-decreasing");
+    }
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+    hipStream_t st = ctx->stream;
+    // topology columns once
+    if ((rc = reserve(ctx, ctx->tr_r, n_atoms * 4))) return rc;
+    if (id && (rc = reserve(ctx, ctx->tr_id, n_atoms * 8))) return rc;
+    if (want_res && (rc = reserve(ctx, ctx->tr_res, (n_residues + 1) * 4))) return rc;
+    RS_HIP(ctx, hipMemcpyAsync(ctx->tr_r.p, radius, n_atoms * 4, hipMemcpyHostToDevice, st));
+    if (id) RS_HIP(ctx, hipMemcpyAsync(ctx->tr_id.p, id, n_atoms * 8, hipMemcpyHostToDevice, st));
+    if (want_res)
+        RS_HIP(ctx, hipMemcpyAsync(ctx->tr_res.p, residue_offsets, (n_residues + 1) * 4,
+                                   hipMemcpyHostToDevice, st));
+    // frames in chunks of at most ~32 M atoms (32-bit indices, bounded workspace)
+    const size_t chunk_frames = std::max<size_t>(1, std::min<size_t>(n_frames, (32u << 20) / n_atoms));
+    std::vector<uint32_t> s_off(chunk_frames + 1);
+    for (size_t f0 = 0; f0 < n_frames; f0 += chunk_frames) {
+        const size_t nf = std::min(chunk_frames, n_frames - f0);
+        const size_t N = nf * n_atoms, R = want_res ? nf * n_residues : 0;
+        if ((rc = reserve(ctx, ctx->tr_xyz, N * 12))) return rc;
+        if ((rc = reserve(ctx, ctx->in_x, N * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->in_y, N * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->in_z, N * 4))) return rc;
+        if ((rc = reserve(ctx, ctx->in_r, N * 4))) return rc;
+        if (id && (rc = reserve(ctx, ctx->in_id, N * 8))) return rc;
+        if ((rc = reserve(ctx, ctx->atom_sasa, N * 4))) return rc;
+        if (want_res) {
+            if ((rc = reserve(ctx, ctx->in_res, (R + 1) * 4))) return rc;
+            if ((rc = reserve(ctx, ctx->out_res, R * 4))) return rc;
+        }
+        RS_HIP(ctx, hipMemcpyAsync(ctx->tr_xyz.p, xyz + f0 * n_atoms * 3, N * 12, hipMemcpyHostToDevice, st));
+        launch_expand_frames((const float *)ctx->tr_xyz.p, (const float *)ctx->tr_r.p,
+                             id ? (const uint64_t *)ctx->tr_id.p : nullptr,
+                             want_res ? (const uint32_t *)ctx->tr_res.p : nullptr, (uint32_t)n_atoms,
+                             (uint32_t)nf, (uint32_t)n_residues, (float *)ctx->in_x.p, (float *)ctx->in_y.p,
+                             (float *)ctx->in_z.p, (float *)ctx->in_r.p, (uint64_t *)ctx->in_id.p,
+                             (uint32_t *)ctx->in_res.p, st);
+        for (size_t f = 0; f <= nf; f++) s_off[f] = (uint32_t)(f * n_atoms);
+        rsasa_device_batch_t bt{};
+        bt.x = (const float *)ctx->in_x.p;
+        bt.y = (const float *)ctx->in_y.p;
+        bt.z = (const float *)ctx->in_z.p;
+        bt.radius = (const float *)ctx->in_r.p;
+        bt.id = id ? (const uint64_t *)ctx->in_id.p : nullptr;
+        bt.structure_offsets_host = s_off.data();
+        bt.n_structures = nf;
+        bt.n_atoms = N;
+        bt.residue_offsets = want_res ? (const uint32_t *)ctx->in_res.p : nullptr;
+        bt.n_residues = R;
+        bt.out_atom_sasa = (float *)ctx->atom_sasa.p;
+        bt.out_residue_sasa = want_res ? (float *)ctx->out_res.p : nullptr;
+        if ((rc = rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr))) return rc;
+        if ((rc = rsasa_batch_wait(ctx))) return rc;
+        if (out_atom_sasa)
+            RS_HIP(ctx, hipMemcpy(out_atom_sasa + f0 * n_atoms, ctx->atom_sasa.p, N * 4, hipMemcpyDeviceToHost));
+        if (want_res)
+            RS_HIP(ctx, hipMemcpy(out_residue_sasa + f0 * n_residues, ctx->out_res.p, R * 4,
+                                  hipMemcpyDeviceToHost));
+    }
+    return RSASA_OK;
 }
 
 int rsasa_segment_sums(rsasa_context_t *ctx, const float *values, size_t n_values,

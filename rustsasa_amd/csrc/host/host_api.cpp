@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -447,6 +448,184 @@ Structure Structure::open(const std::string &path)
     const std::string ext = upper(path.substr(path.find_last_of('.') == std::string::npos ? path.size() : path.find_last_of('.')));
     if (ext == ".CIF" || ext == ".MMCIF") return from_mmcif_text(ss.str());
     return from_pdb_text(ss.str());
+}
+
+// ------------------------------------------------------------------ output --
+
+namespace {
+
+void json_string(std::string &o, const std::string &s)
+{
+    o += '"';
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { o += '\\'; o += (char)c; }
+        else if (c < 0x20) { char b[8]; std::snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+        else o += (char)c;
+    }
+    o += '"';
+}
+
+// shortest decimal that round-trips the f32 (what serde_json prints for f32)
+void json_f32(std::string &o, float v)
+{
+    char b[32];
+    for (int prec = 1; prec <= 9; prec++) {
+        std::snprintf(b, sizeof b, "%.*g", prec, (double)v);
+        if (std::strtof(b, nullptr) == v) break;
+    }
+    std::string t = b;
+    if (t.find_first_of(".eEn") == std::string::npos) t += ".0";  // serde writes 0.0, 12.0
+    o += t;
+}
+
+}  // namespace
+
+std::string sasa_result_to_json(const std::vector<float> &v)
+{
+    std::string o = "{\"Atom\":[";
+    for (size_t i = 0; i < v.size(); i++) { if (i) o += ','; json_f32(o, v[i]); }
+    return o + "]}";
+}
+
+std::string sasa_result_to_json(const std::vector<ResidueResult> &v)
+{
+    std::string o = "{\"Residue\":[";
+    for (size_t i = 0; i < v.size(); i++) {
+        if (i) o += ',';
+        o += "{\"serial_number\":" + std::to_string(v[i].serial_number) + ",\"insertion_code\":";
+        json_string(o, v[i].insertion_code);
+        o += ",\"value\":";
+        json_f32(o, v[i].value);
+        o += ",\"name\":";
+        json_string(o, v[i].name);
+        o += std::string(",\"is_polar\":") + (v[i].is_polar ? "true" : "false") + ",\"chain_id\":";
+        json_string(o, v[i].chain_id);
+        o += '}';
+    }
+    return o + "]}";
+}
+
+std::string sasa_result_to_json(const std::vector<ChainResult> &v)
+{
+    std::string o = "{\"Chain\":[";
+    for (size_t i = 0; i < v.size(); i++) {
+        if (i) o += ',';
+        o += "{\"name\":";
+        json_string(o, v[i].name);
+        o += ",\"value\":";
+        json_f32(o, v[i].value);
+        o += '}';
+    }
+    return o + "]}";
+}
+
+std::string sasa_result_to_json(const ProteinResult &v)
+{
+    std::string o = "{\"Protein\":{\"global_total\":";
+    json_f32(o, v.global_total);
+    o += ",\"polar_total\":";
+    json_f32(o, v.polar_total);
+    o += ",\"non_polar_total\":";
+    json_f32(o, v.non_polar_total);
+    return o + "}}";
+}
+
+// io.rs:25-30: every atom of the model, in order, takes v[i]
+bool sasa_result_to_protein_object(Structure &pdb, const std::vector<float> &v, std::string *err)
+{
+    if (pdb.atom_count() != v.size()) {
+        if (err) *err = "atom-level result has " + std::to_string(v.size()) + " values for " +
+                        std::to_string(pdb.atom_count()) + " atoms (filtered atoms cannot be mapped back)";
+        return false;
+    }
+    size_t i = 0;
+    for (auto &c : pdb.chains)
+        for (auto &r : c.residues)
+            for (auto &f : r.conformers)
+                for (auto &a : f.atoms) a.b_factor = (double)v[i++];
+    return true;
+}
+
+// io.rs:31-43
+bool sasa_result_to_protein_object(Structure &pdb, const std::vector<ResidueResult> &v, std::string *err)
+{
+    size_t i = 0;
+    for (auto &c : pdb.chains)
+        for (auto &r : c.residues) {
+            if (i >= v.size() || v[i].serial_number != r.serial_number) {
+                if (err) *err = "residue-level result does not line up with the structure";
+                return false;
+            }
+            for (auto &f : r.conformers)
+                for (auto &a : f.atoms) a.b_factor = (double)v[i].value;
+            i++;
+        }
+    return true;
+}
+
+// io.rs:44-54
+bool sasa_result_to_protein_object(Structure &pdb, const std::vector<ChainResult> &v, std::string *err)
+{
+    if (v.size() != pdb.chains.size()) {
+        if (err) *err = "chain-level result does not line up with the structure";
+        return false;
+    }
+    for (size_t i = 0; i < pdb.chains.size(); i++) {
+        if (v[i].name != pdb.chains[i].id) {
+            if (err) *err = "chain-level result does not line up with the structure";
+            return false;
+        }
+        for (auto &r : pdb.chains[i].residues)
+            for (auto &f : r.conformers)
+                for (auto &a : f.atoms) a.b_factor = (double)v[i].value;
+    }
+    return true;
+}
+
+// io.rs:55-61
+bool sasa_result_to_protein_object(Structure &pdb, const ProteinResult &v, std::string *)
+{
+    for (auto &c : pdb.chains)
+        for (auto &r : c.residues)
+            for (auto &f : r.conformers)
+                for (auto &a : f.atoms) a.b_factor = (double)v.global_total;
+    return true;
+}
+
+std::string Structure::to_pdb_text() const
+{
+    std::string o;
+    char line[96];
+    for (const auto &c : chains) {
+        for (const auto &r : c.residues)
+            for (const auto &f : r.conformers)
+                for (const auto &a : f.atoms) {
+                    // atom names shorter than four characters start in column 14 unless the
+                    // element symbol has two letters
+                    std::string name = a.name;
+                    if (name.size() < 4 && a.element.size() < 2) name = " " + name;
+                    std::snprintf(line, sizeof line,
+                                  "%-6s%5zu %-4s%1s%3s %1s%4lld%1s   %8.3f%8.3f%8.3f%6.2f%6.2f          %2s  \n",
+                                  a.hetero ? "HETATM" : "ATOM", a.serial % 100000, name.c_str(),
+                                  f.alt_loc.substr(0, 1).c_str(), f.name.substr(0, 3).c_str(),
+                                  c.id.substr(0, 1).c_str(), (long long)(r.serial_number % 10000),
+                                  r.insertion_code.substr(0, 1).c_str(), a.x, a.y, a.z, a.occupancy,
+                                  a.b_factor, a.element.c_str());
+                    o += line;
+                }
+        o += "TER\n";
+    }
+    o += "END\n";
+    return o;
+}
+
+void Structure::save_pdb(const std::string &path) const
+{
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot write " + path);
+    const std::string t = to_pdb_text();
+    f.write(t.data(), (std::streamsize)t.size());
+    if (!f) throw std::runtime_error("write failed: " + path);
 }
 
 // ------------------------------------------------------------------ levels --

@@ -154,42 +154,39 @@ int main(int argc, char **argv)
         return 66;
     }
     try {
+        const char *bf_out = nullptr;  // --bfactor-out FILE: write the values into b-factors, save as PDB
+        for (int i = 3; i + 1 < argc; i++)
+            if (!std::strcmp(argv[i], "--bfactor-out")) bf_out = argv[i + 1];
+        auto emit = [&](const auto &value) -> int {
+            std::printf("%s\n", sasa_result_to_json(value).c_str());
+            if (bf_out) {
+                std::string err;
+                if (!sasa_result_to_protein_object(pdb, value, &err)) {
+                    std::fprintf(stderr, "%s\n", err.c_str());
+                    return 3;
+                }
+                pdb.save_pdb(bf_out);
+            }
+            return 0;
+        };
         if (level == "atom") {
             auto r = make<AtomLevel>(argc, argv).process(pdb);
             if (!r.ok()) return fail(r);
-            std::printf("{\"Atom\":[");
-            for (size_t i = 0; i < r.value.size(); i++) std::printf("%s%.9g", i ? "," : "", r.value[i]);
-            std::printf("]}\n");
+            return emit(r.value);
         } else if (level == "residue") {
             auto r = make<ResidueLevel>(argc, argv).process(pdb);
             if (!r.ok()) return fail(r);
-            std::printf("{\"Residue\":[");
-            for (size_t i = 0; i < r.value.size(); i++) {
-                const auto &v = r.value[i];
-                std::printf("%s{\"serial_number\":%lld,\"insertion_code\":", i ? "," : "", (long long)v.serial_number);
-                print_str(v.insertion_code);
-                std::printf(",\"value\":%.9g,\"name\":", v.value);
-                print_str(v.name);
-                std::printf(",\"is_polar\":%s,\"chain_id\":", v.is_polar ? "true" : "false");
-                print_str(v.chain_id);
-                std::printf("}");
-            }
-            std::printf("]}\n");
+            return emit(r.value);
         } else if (level == "chain") {
             auto r = make<ChainLevel>(argc, argv).process(pdb);
             if (!r.ok()) return fail(r);
-            std::printf("{\"Chain\":[");
-            for (size_t i = 0; i < r.value.size(); i++) {
-                std::printf("%s{\"name\":", i ? "," : "");
-                print_str(r.value[i].name);
-                std::printf(",\"value\":%.9g}", r.value[i].value);
-            }
-            std::printf("]}\n");
+            return emit(r.value);
         } else if (level == "protein") {
             auto r = make<ProteinLevel>(argc, argv).process(pdb);
             if (!r.ok()) return fail(r);
-            std::printf("{\"Protein\":{\"global_total\":%.9g,\"polar_total\":%.9g,\"non_polar_total\":%.9g}}\n",
-                        r.value.global_total, r.value.polar_total, r.value.non_polar_total);
+            return emit(r.value);
+        } else if (level == "rewrite") {  // reader -> writer round trip, no GPU
+            std::printf("%s", pdb.to_pdb_text().c_str());
         } else if (level == "parse") {  // reader only (no GPU): atom / residue / chain counts
             size_t res = 0;
             for (const auto &c : pdb.chains) res += c.residues.size();

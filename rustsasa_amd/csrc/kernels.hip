@@ -13,6 +13,8 @@
 // src/lib.rs:143-144).  Citations are relative to the reference tree.
 #include "device_utils.h"
 
+#include <algorithm>
+
 namespace rsasa {
 
 namespace {
@@ -256,6 +258,41 @@ void launch_grid_build(const BatchView &b, hipStream_t stream)
     hipLaunchKernelGGL(k_scan_apply, dim3(kScanBlocks), dim3(256), 0, stream, b);
     if (b.n_atoms)
         hipLaunchKernelGGL(k_scatter, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);
+}
+
+// Trajectory frames: xyz is frame-major [n_frames][n_atoms][3] (what MD readers hand over);
+// radii, ids and residue offsets are given once and tiled over the frames.
+__global__ __launch_bounds__(256) void k_expand_frames(const float *xyz, const float *radius,
+                                                       const uint64_t *id, const uint32_t *res_off,
+                                                       uint32_t n_atoms, uint32_t n_frames,
+                                                       uint32_t n_res, float *x, float *y, float *z,
+                                                       float *r, uint64_t *id_out, uint32_t *res_out)
+{
+    const uint64_t total = (uint64_t)n_atoms * n_frames;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) {
+        const uint32_t a = (uint32_t)(i % n_atoms);
+        x[i] = xyz[3 * i + 0];
+        y[i] = xyz[3 * i + 1];
+        z[i] = xyz[3 * i + 2];
+        r[i] = radius[a];
+        if (id) id_out[i] = id[a];
+    }
+    const uint64_t total_res = (uint64_t)n_res * n_frames;
+    if (res_off && i <= total_res) {
+        const uint32_t f = (uint32_t)(i / n_res), k = (uint32_t)(i % n_res);
+        res_out[i] = i == total_res ? n_atoms * n_frames : f * n_atoms + res_off[k];
+    }
+}
+
+void launch_expand_frames(const float *xyz, const float *radius, const uint64_t *id,
+                          const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t n_res,
+                          float *x, float *y, float *z, float *r, uint64_t *id_out,
+                          uint32_t *res_out, hipStream_t stream)
+{
+    const uint64_t n = std::max<uint64_t>((uint64_t)n_atoms * n_frames, (uint64_t)n_res * n_frames + 1);
+    hipLaunchKernelGGL(k_expand_frames, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, xyz,
+                       radius, id, res_off, n_atoms, n_frames, n_res, x, y, z, r, id_out, res_out);
 }
 
 void launch_residue_sums(const BatchView &b, hipStream_t stream)

@@ -110,6 +110,27 @@ class Context:
             probe_radius, n_points, ptr(atom_out), ptr(ro), n_res, ptr(res_out)))
         return atom_out, res_out
 
+    # ---- MD trajectory: one topology, many frames --------------------------
+    def calculate_sasa_trajectory(self, xyz, radius, ids=None, probe_radius: float = 1.4,
+                                  n_points: int = 100, residue_offsets=None, want_atoms: bool = True):
+        """xyz: [n_frames, n_atoms, 3] float32 (frame-major); returns ([F, N] atom values or None,
+        [F, R] residue sums or None)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n_frames, n_atoms = xyz.shape[0], xyz.shape[1]
+        radius = _f32(radius)
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        atom_out = np.zeros((n_frames, n_atoms), np.float32) if want_atoms else None
+        ro = res_out = None
+        n_res = 0
+        if residue_offsets is not None:
+            ro = np.ascontiguousarray(residue_offsets, dtype=np.uint32)
+            n_res = ro.shape[0] - 1
+            res_out = np.zeros((n_frames, n_res), np.float32)
+        self._check(self._lib.rsasa_calculate_sasa_trajectory(
+            self._h, ptr(xyz), n_frames, n_atoms, ptr(radius), ptr(ids), probe_radius, n_points,
+            ptr(atom_out), ptr(ro), n_res, ptr(res_out)))
+        return atom_out, res_out
+
     # ---- many structures, buffers already in HBM --------------------------
     def enqueue_device(self, x, y, z, radius, ids, structure_offsets_host: np.ndarray,
                        out_atom_sasa=None, residue_offsets=None, out_residue_sasa=None,

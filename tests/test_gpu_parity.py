@@ -385,3 +385,21 @@ def test_hypothesis_random_clouds(ctx):
         got = ctx.calculate_sasa_soa(c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy(), r, ids, probe, n_points)
         want = po.calculate_sasa_internal(c[:, 0], c[:, 1], c[:, 2], r, ids, probe, n_points, 8)
         assert np.array_equal(got, want), (trial, n, box, probe, n_points)
+
+
+def test_trajectory_mode(ctx):
+    """Frames of one topology = independent structures; radii / ids / residues given once."""
+    xyz, r, res, ids = bw.fixture_soa("1jcd.pdb")
+    rng = np.random.default_rng(8)
+    frames = np.stack([(xyz + rng.normal(scale=0.3, size=xyz.shape)) for _ in range(7)]).astype(np.float32)
+    ro = res.astype(np.uint32)
+    atom, rsum = ctx.calculate_sasa_trajectory(frames, r, ids, PROBE, 100, residue_offsets=ro)
+    assert atom.shape == (7, len(r)) and rsum.shape == (7, len(ro) - 1)
+    for f in range(7):
+        want = po.calculate_sasa_internal(frames[f, :, 0], frames[f, :, 1], frames[f, :, 2], r, ids,
+                                          PROBE, 100, 8)
+        assert np.array_equal(atom[f], want)
+        assert np.array_equal(rsum[f], po.residue_sums(want, ro))
+    only_res = ctx.calculate_sasa_trajectory(frames, r, None, PROBE, 100, residue_offsets=ro,
+                                             want_atoms=False)
+    assert only_res[0] is None and np.array_equal(only_res[1], rsum)

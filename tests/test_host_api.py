@@ -267,4 +267,50 @@ def test_process_files_matches_oracle(tmp_path, batch):
     prot = json.loads(p.stdout)["results"]
     single = run_cli("protein", "example.cif")["Protein"]
     i_cif = paths.index(sio.data_path("example.cif"))
-    assert prot[i_cif] == [single["global_total"], single["polar_total"], single["non_polar_total"]]
+    assert np.array_equal(np.array(prot[i_cif], np.float32),
+                          np.array([single["global_total"], single["polar_total"],
+                                    single["non_polar_total"]], np.float32))
+
+
+# ---- writers (reference src/utils/io.rs) ---------------------------------------------
+
+@pytest.mark.parametrize("name", ["1jcd.pdb", "151L_H3.pdb", "2drt.pdb"])
+def test_pdb_writer_round_trip(name):
+    p = subprocess.run([CLI, "rewrite", sio.data_path(name)], capture_output=True, text=True)
+    assert p.returncode == 0
+    src = [l.rstrip("\n") for l in open(sio.data_path(name)) if l.startswith(("ATOM  ", "HETATM"))]
+    out = [l for l in p.stdout.split("\n") if l.startswith(("ATOM  ", "HETATM"))]
+    assert len(src) == len(out)
+    # chains are written grouped (pdbtbx merges records of one chain id), so compare as sets
+    # of the fixed columns 1-66 + element
+    key = lambda l: (l[:66], l[76:78].strip())  # noqa: E731
+    assert sorted(map(key, src)) == sorted(map(key, out))
+
+
+@pytest.mark.gpu
+def test_bfactor_write_back(tmp_path):
+    out = str(tmp_path / "res.pdb")
+    got = run_cli("residue", "1jcd.pdb", "--bfactor-out", out)["Residue"]
+    atoms = sio.read_pdb(out)
+    bf = {}
+    for l in open(out):
+        if l.startswith(("ATOM  ", "HETATM")):
+            bf.setdefault((l[21], int(l[22:26])), set()).add(float(l[60:66]))
+    assert len(atoms) == 1238
+    for g in got:
+        vals = bf[(g["chain_id"], g["serial_number"])]
+        assert len(vals) == 1 and abs(vals.pop() - g["value"]) <= 0.005 + 1e-6
+    # atom level with filtered atoms cannot be mapped back (the reference would index out of range)
+    p = subprocess.run([CLI, "atom", sio.data_path("1jcd.pdb"), "--bfactor-out", out], capture_output=True, text=True)
+    assert p.returncode == 3 and "cannot be mapped back" in p.stderr
+
+
+@pytest.mark.gpu
+def test_json_shape_matches_serde():
+    p = subprocess.run([CLI, "residue", sio.data_path("2drt.pdb")], capture_output=True, text=True)
+    text = p.stdout.strip()
+    assert text.startswith('{"Residue":[{"serial_number":') and text.endswith("]}")
+    first = json.loads(text)["Residue"][0]
+    assert list(first.keys()) == ["serial_number", "insertion_code", "value", "name", "is_polar", "chain_id"]
+    prot = subprocess.run([CLI, "protein", sio.data_path("2drt.pdb")], capture_output=True, text=True).stdout
+    assert list(json.loads(prot)["Protein"].keys()) == ["global_total", "polar_total", "non_polar_total"]
