@@ -132,10 +132,12 @@ __global__ __launch_bounds__(1024) void k_finalize_grids(BatchView b)
 __global__ __launch_bounds__(256) void k_zero_cells(BatchView b)
 {
     if (batch_aborted(b.status)) return;
-    const uint64_t n = b.status->total_cells + 1;  // + end sentinel
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+    // + end sentinel, rounded up to whole 16-byte vectors (the buffer has the slack)
+    const uint64_t n4 = (b.status->total_cells + 1 + 3) / 4;
+    uint4 *c4 = reinterpret_cast<uint4 *>(b.cells);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (uint64_t)gridDim.x * blockDim.x)
-        b.cells[i] = 0u;
+        c4[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // Count atoms per cell (spatial_grid.rs:53-62); the atomic's return value is
@@ -172,8 +174,13 @@ __global__ __launch_bounds__(256) void k_scan_reduce(BatchView b)
     __shared__ uint32_t smem[4];
     uint64_t begin, end;
     scan_range(b, begin, end);
+    // 16-byte loads: `begin` is a multiple of 1024 entries and the tail past `end` was zeroed
     uint32_t sum = 0;
-    for (uint64_t i = begin + threadIdx.x; i < end; i += blockDim.x) sum += b.cells[i];
+    const uint4 *c4 = reinterpret_cast<const uint4 *>(b.cells);
+    for (uint64_t i = begin / 4 + threadIdx.x; i < (end + 3) / 4; i += blockDim.x) {
+        const uint4 v = c4[i];
+        sum += v.x + v.y + v.z + v.w;
+    }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) sum += __shfl_xor(sum, d, kWave);
     if (lane_id() == 0) smem[threadIdx.x / kWave] = sum;
@@ -197,19 +204,16 @@ __global__ __launch_bounds__(256) void k_scan_apply(BatchView b)
     uint64_t begin, end;
     scan_range(b, begin, end);
     uint32_t running = b.scan_block_sums[blockIdx.x];
+    uint4 *c4 = reinterpret_cast<uint4 *>(b.cells);
     for (uint64_t tile = begin; tile < end; tile += 1024) {
-        uint64_t i0 = tile + (uint64_t)threadIdx.x * 4;
-        uint32_t v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i0 + k < end) ? b.cells[i0 + k] : 0u;
-        uint32_t tsum = v[0] + v[1] + v[2] + v[3], total;
+        const uint64_t i0 = tile + (uint64_t)threadIdx.x * 4;
+        // whole 16-byte vectors: entries past `end` inside the last vector are zero (k_zero_cells)
+        const bool live = i0 < end;
+        const uint4 v = live ? c4[i0 / 4] : make_uint4(0u, 0u, 0u, 0u);
+        uint32_t tsum = v.x + v.y + v.z + v.w, total;
         uint32_t inc = block_incl_scan<4>(tsum, smem, total);
-        uint32_t ex = running + inc - tsum;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < end) b.cells[i0 + k] = ex;
-            ex += v[k];
-        }
+        const uint32_t ex = running + inc - tsum;
+        if (live) c4[i0 / 4] = make_uint4(ex, ex + v.x, ex + v.x + v.y, ex + v.x + v.y + v.z);
         running += total;
     }
 }
