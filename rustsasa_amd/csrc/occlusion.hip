@@ -9,8 +9,9 @@
 //      spatial_grid.rs:47: max_search / cell_size is exactly 2 in f32), culled and trimmed with
 //      a conservative lower bound on the distance.
 //   Then per atom:
-//   1. the runs are cut into 16-atom segments (DPP prefix sum, LDS table);
-//   2. SWEEP: four segments per iteration (16 lanes each): the reference's candidate rule
+//   1. the run lengths are prefix-summed (DPP); a 256-bit mask of run starts and a per-run
+//      `start - prefix` table map every flat position of the concatenated runs to its atom;
+//   2. SWEEP: 64 flat positions per iteration: the reference's candidate rule
 //      d^2 <= (r_i + max_r + 2p)^2 (spatial_grid.rs:307-308,335); accepted atoms' indices are
 //      appended to the wave's LDS list;
 //   3. PREP (lane = candidate): id rule (:314), v and limit_j (lib.rs:128-136); the list is
