@@ -1,0 +1,50 @@
+/* Plain C99 consumer of include/rustsasa_amd.h: the header must compile as C and the
+ * library must link and behave without any C++/HIP types on the caller's side.
+ * Exit code 0 = ok on a GPU host, 0 with "no device" printed on a GPU-less host. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rustsasa_amd.h"
+
+int main(void)
+{
+    if (rsasa_abi_version() != RSASA_ABI_VERSION) return 10;
+    if (sizeof(rsasa_atom_t) != 24) return 11;
+    int n_dev = -1;
+    if (rsasa_device_count(&n_dev) != RSASA_OK) return 12;
+    float sx[100], sy[100], sz[100];
+    if (rsasa_sphere_points(100, sx, sy, sz) != RSASA_OK || sz[0] != 1.0f) return 13;
+
+    rsasa_context_t *ctx = NULL;
+    int rc = rsasa_context_create(0, &ctx);
+    if (n_dev == 0) {
+        if (rc != RSASA_ERR_NO_DEVICE || ctx != NULL) return 14;
+        printf("no device: %s\n", rsasa_status_string(rc));
+        return 0;
+    }
+    if (rc != RSASA_OK) return 15;
+
+    /* two overlapping spheres (reference tests/sanity.rs:64-85) + one far away */
+    rsasa_atom_t atoms[3];
+    memset(atoms, 0, sizeof atoms);
+    atoms[0].radius = atoms[1].radius = atoms[2].radius = 2.0f;
+    atoms[1].position[0] = 4.0f;
+    atoms[2].position[0] = 40.0f;
+    atoms[0].id = 1; atoms[1].id = 2; atoms[2].id = 3;
+    float out[3] = {-1.f, -1.f, -1.f};
+    rc = rsasa_calculate_sasa_internal(ctx, atoms, 3, 1.4f, 5000, -1, out);
+    if (rc != RSASA_OK) { printf("%s\n", rsasa_context_last_error(ctx)); return 16; }
+    const double pi = 3.14159265358979323846, r = 3.4;
+    const double full = 4 * pi * r * r, exposed = full - 2 * pi * r * (r - 2.0);
+    if (out[0] < exposed * 0.99 || out[0] > exposed * 1.01) return 17;
+    if (out[1] != out[0]) return 18;
+    if (out[2] < full * 0.999 || out[2] > full * 1.001) return 19;
+    /* empty input is valid and touches nothing */
+    if (rsasa_calculate_sasa_internal(ctx, NULL, 0, 1.4f, 100, 1, NULL) != RSASA_OK) return 20;
+    /* invalid arguments are reported, not crashed on */
+    if (rsasa_calculate_sasa_internal(ctx, atoms, 3, 1.4f, 0, 1, out) != RSASA_ERR_INVALID_ARGUMENT) return 21;
+    if (rsasa_context_destroy(ctx) != RSASA_OK) return 22;
+    printf("abi ok: %.3f %.3f %.3f\n", out[0], out[1], out[2]);
+    return 0;
+}
