@@ -165,11 +165,12 @@ int rsasa_segment_sums(rsasa_context_t *ctx, const float *values, size_t n_value
  * completed batch are returned by rsasa_context_get_timings. */
 typedef struct rsasa_timings {
     float grid_build_ms;   /* bounds + binning + scan + scatter kernels */
-    float occlusion_ms;    /* the occlusion kernel alone */
+    float occlusion_ms;    /* the occlusion kernels alone (fast kernel + general kernel over deferred atoms) */
     float aggregate_ms;    /* residue sums */
     float total_ms;        /* first kernel start -> last kernel end */
     uint64_t n_cells;      /* total grid cells of the batch */
     uint64_t n_atoms;
+    uint64_t n_deferred;   /* atoms the fast occlusion kernel left to the general one */
 } rsasa_timings_t;
 
 int rsasa_context_enable_timing(rsasa_context_t *ctx, int enable);

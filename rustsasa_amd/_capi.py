@@ -54,7 +54,7 @@ class Timings(C.Structure):
     """rsasa_timings_t"""
     _fields_ = [("grid_build_ms", C.c_float), ("occlusion_ms", C.c_float),
                 ("aggregate_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_cells", C.c_uint64), ("n_atoms", C.c_uint64)]
+                ("n_cells", C.c_uint64), ("n_atoms", C.c_uint64), ("n_deferred", C.c_uint64)]
 
 
 # every symbol include/rustsasa_amd.h declares: name -> (restype, argtypes)

@@ -306,7 +306,7 @@ int wait_pending(rsasa_context *ctx)
                 (void)hipEventElapsedTime(&o, ctx->ev[1], ctx->ev[2]);
                 (void)hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]);
                 (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]);
-                ctx->timings = rsasa_timings_t{g, o, a, t, stt.total_cells, pd.batch.n_atoms};
+                ctx->timings = rsasa_timings_t{g, o, a, t, stt.total_cells, pd.batch.n_atoms, stt.deferred};
                 ctx->timings_valid = true;
             }
             pd.active = false;

@@ -40,7 +40,7 @@ struct BatchStatus {
     uint32_t overflow;        // total cells exceed the workspace capacity: re-run after growing
     uint32_t grid_too_large;  // some structure needs more than 2^31 cells
     uint32_t bad_input;       // probe + max_r <= 0 or non-finite bounds
-    uint32_t pad;
+    uint32_t deferred;        // atoms k_occlusion_fast left to the general kernel (list in cell_of)
     uint64_t total_cells;
     uint64_t reserved;
 };
@@ -66,7 +66,8 @@ struct BatchView {
     StructAcc *acc;
     StructGrid *grids;
     uint32_t *sid;                // structure of atom i (same in input and cell-sorted order)
-    uint32_t *cell_of, *rank_of;  // global cell index / arrival rank inside the cell
+    uint32_t *cell_of, *rank_of;  // global cell index / arrival rank inside the cell (dead after the sort:
+                                  // cell_of then holds the occlusion kernels' deferred-atom list)
     uint32_t *cells;              // counts, then exclusive starts (cell_capacity + 1 entries)
     uint64_t cell_capacity;
     uint32_t *scan_block_sums;
@@ -83,7 +84,8 @@ struct BatchView {
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
-    int kernel_version = 3;       // 0 = all-pairs reference kernel, 3 = culled sweep + two-phase point tests
+    int kernel_version = 4;       // 0 = all-pairs reference kernel, 3 = general culled-sweep kernel for every atom,
+                                  // 4 = straight-line fast kernel + the general kernel for the atoms it defers
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
     uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
 };

@@ -28,6 +28,7 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
         status->overflow = 0;
         status->grid_too_large = 0;
         status->bad_input = 0;
+        status->deferred = 0;
         status->total_cells = 0;
     }
     if (s >= n_structures) return;

@@ -51,6 +51,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m)
 
 
 #include "occlusion_v3.inc"
+#include "occlusion_fast.inc"
 
 template <int NCH>
 void launch_v0(const OccArgs &a, hipStream_t stream)
@@ -84,7 +85,23 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     }
     a.atoms_per_wave = min(a.atoms_per_wave, (uint32_t)kMaxAtomsPerWave);
     a.n_blocks = cdiv(cdiv(b.n_atoms, a.atoms_per_wave), 4);
-    const OccArgs3 a3 = make_args3(a);
+    OccArgs3 a3 = make_args3(a);
+    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && n_chunks <= 2 &&
+                      lat.n_points - lat.n_fused <= kFastMaxRem;
+    if (fast) {
+        // straight-line kernel for every atom it can take; the rest go through the general kernel
+        a3.work_list_out = b.cell_of;  // dead since k_scatter
+        a3.work_count_out = &b.status->deferred;
+        if (b.id) hipLaunchKernelGGL((k_occlusion_fast<true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        else hipLaunchKernelGGL((k_occlusion_fast<false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        a3.work_list = b.cell_of;
+        a3.work_count = &b.status->deferred;
+        a3.atoms_per_wave = 1;
+        const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), 2048u);
+        if (b.id) hipLaunchKernelGGL((k_occlusion_v3<2, true, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+        else hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+        return;
+    }
     if (tune.debug_stop != 0) {  // timing ablation build (tools/ablate.sh); results are wrong
         if (b.id) hipLaunchKernelGGL((k_occlusion_v3<2, true, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
         else hipLaunchKernelGGL((k_occlusion_v3<2, false, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);

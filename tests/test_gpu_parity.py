@@ -310,7 +310,9 @@ def test_full_proteome_properties(ctx):
 @pytest.mark.parametrize("env", [{"RSASA_OCCLUSION_KERNEL": "0"},
                                  {"RSASA_OCCLUSION_KERNEL": "2", "RSASA_ATOMS_PER_WAVE": "5"},
                                  {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "1"},
-                                 {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "7"}])
+                                 {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "7"},
+                                 {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "1"},
+                                 {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "3"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """Every occlusion kernel variant / wave schedule gives bit-identical results."""
     import rustsasa_amd
@@ -403,3 +405,33 @@ def test_trajectory_mode(ctx):
     only_res = ctx.calculate_sasa_trajectory(frames, r, None, PROBE, 100, residue_offsets=ro,
                                              want_atoms=False)
     assert only_res[0] is None and np.array_equal(only_res[1], rsum)
+
+
+def test_fast_kernel_defers_dense_atoms_inside_a_mixed_batch(ctx):
+    """Kernel 4 = straight-line fast kernel + the general kernel over the atoms it defers (more
+    than 256 atoms in the culled runs, or a candidate list past the LDS list).  A batch mixing
+    protein-like structures with a dense blob must use both, and still match the oracle."""
+    rng = np.random.default_rng(99)
+    prot = bw.synthetic_proteome(6, seed=5)
+    n_blob = 1500
+    blob = rng.normal(scale=4.0, size=(n_blob, 3)).astype(np.float32)      # ~10x protein density
+    x = np.concatenate([prot.x, blob[:, 0]])
+    y = np.concatenate([prot.y, blob[:, 1]])
+    z = np.concatenate([prot.z, blob[:, 2]])
+    r = np.concatenate([prot.radius, rng.uniform(1.2, 2.0, n_blob).astype(np.float32)])
+    ids = np.arange(len(x), dtype=np.uint64)
+    so = np.concatenate([prot.structure_offsets, [len(x)]]).astype(np.uint32)
+    b = bw.Batch(x, y, z, r, ids, so, so)
+    ctx.enable_timing(True)
+    try:
+        atom, _, k = _device_run(ctx, b, want_res=False)
+        n_deferred = ctx.timings()["n_deferred"]
+    finally:
+        ctx.enable_timing(False)
+    want = po.calculate_sasa_batch(x, y, z, r, ids, so, PROBE, 100, 8, threads=8)
+    assert np.array_equal(atom, want)
+    assert 0 < n_deferred < len(x)
+    _, _, k_blob = po.calculate_sasa_internal(blob[:, 0], blob[:, 1], blob[:, 2], r[-n_blob:], ids[-n_blob:],
+                                              PROBE, 100, 8, return_details=True)
+    assert np.array_equal(k[-n_blob:], k_blob)
+    assert k_blob.max() > 160
