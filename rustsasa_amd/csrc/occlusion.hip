@@ -76,6 +76,8 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         else launch_v0<16>(a, stream);
         return;
     }
+    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && n_chunks <= 2 &&
+                      lat.n_points - lat.n_fused <= kFastMaxRem;
     if (tune.atoms_per_wave > 0) {
         a.atoms_per_wave = tune.atoms_per_wave;
     } else {
@@ -83,17 +85,18 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         const uint32_t waves_full = 256u * 4u * 8u * 4u;
         a.atoms_per_wave = max(1u, b.n_atoms / waves_full);
     }
-    a.atoms_per_wave = min(a.atoms_per_wave, (uint32_t)kMaxAtomsPerWave);
+    a.atoms_per_wave = min(a.atoms_per_wave, (uint32_t)(fast ? kFastAtomsPerWave : kMaxAtomsPerWave));
     a.n_blocks = cdiv(cdiv(b.n_atoms, a.atoms_per_wave), 4);
     OccArgs3 a3 = make_args3(a);
-    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && n_chunks <= 2 &&
-                      lat.n_points - lat.n_fused <= kFastMaxRem;
     if (fast) {
         // straight-line kernel for every atom it can take; the rest go through the general kernel
         a3.work_list_out = b.cell_of;  // dead since k_scatter
         a3.work_count_out = &b.status->deferred;
-        if (b.id) hipLaunchKernelGGL((k_occlusion_fast<true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
-        else hipLaunchKernelGGL((k_occlusion_fast<false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        const bool rem = lat.n_points != lat.n_fused;
+        if (b.id && rem) hipLaunchKernelGGL((k_occlusion_fast<true, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        else if (b.id) hipLaunchKernelGGL((k_occlusion_fast<true, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        else if (rem) hipLaunchKernelGGL((k_occlusion_fast<false, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        else hipLaunchKernelGGL((k_occlusion_fast<false, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
         a3.work_list = b.cell_of;
         a3.work_count = &b.status->deferred;
         a3.atoms_per_wave = 1;
