@@ -85,7 +85,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         const uint32_t waves_full = 256u * 4u * 8u * 4u;
         a.atoms_per_wave = max(1u, b.n_atoms / waves_full);
     }
-    a.atoms_per_wave = min(a.atoms_per_wave, (uint32_t)(fast ? kFastAtomsPerWave : kMaxAtomsPerWave));
+    // (the fast kernel takes its atoms in groups of kFastAtomsPerWave, so any count works there)
+    a.atoms_per_wave = min(a.atoms_per_wave, fast ? 4u * (uint32_t)kFastAtomsPerWave : (uint32_t)kMaxAtomsPerWave);
+    if (fast && a.atoms_per_wave > (uint32_t)kFastAtomsPerWave)
+        a.atoms_per_wave -= a.atoms_per_wave % (uint32_t)kFastAtomsPerWave;
     a.n_blocks = cdiv(cdiv(b.n_atoms, a.atoms_per_wave), 4);
     OccArgs3 a3 = make_args3(a);
     if (fast) {

@@ -1,3 +1,3 @@
-for apw in 5 8 10; do
+for apw in "$@"; do
   RSASA_ATOMS_PER_WAVE=$apw timeout 200 python bench.py --steps 10 --warmup 2 --cpu-seconds 0 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('apw', $apw, d['kernel_ms'], d['value'])"
 done
