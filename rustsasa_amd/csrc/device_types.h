@@ -15,7 +15,11 @@ struct StructGrid {
     float max_r;                   // fold(0.0, max) of the radii           (lib.rs:259-262)
     float cell_size;               // probe + max_r                        (lib.rs:76)
     uint32_t n_cells;
-    uint32_t pad[5];
+    uint32_t atom_begin;           // first atom of the structure in input order
+    uint32_t n_atoms;
+    uint32_t sorted_base;          // first position of the structure in the cell-sorted arrays
+    uint32_t in_lds;               // 1: binned by k_sort_small (cells fit the LDS), 0: by the batch-wide kernels
+    uint32_t pad;
 };
 static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
 
@@ -25,6 +29,8 @@ struct StructAcc {
     int min_x, min_y, min_z;
     int max_x, max_y, max_z;
     int max_r;
+    uint32_t n_atoms;      // atoms of the structure (sum over its bounds workgroups)
+    uint32_t first_atom;   // smallest atom index of the structure
     int pad;
 };
 
@@ -41,8 +47,10 @@ struct BatchStatus {
     uint32_t grid_too_large;  // some structure needs more than 2^31 cells
     uint32_t bad_input;       // probe + max_r <= 0 or non-finite bounds
     uint32_t deferred;        // atoms k_occlusion_fast left to the general kernel (list in cell_of)
-    uint64_t total_cells;
-    uint64_t reserved;
+    uint64_t total_cells;     // cells of the batch-wide array in use (LDS-binned structures first, then the tail)
+    uint64_t tail_cell_begin; // first cell of the structures binned by the batch-wide kernels (multiple of 1024)
+    uint32_t tail_atom_base;  // their first position in the cell-sorted arrays (= atoms of the LDS-binned structures)
+    uint32_t pad[3];
 };
 
 struct Lattice {
@@ -65,7 +73,8 @@ struct BatchView {
     const Segment *segments;
     StructAcc *acc;
     StructGrid *grids;
-    uint32_t *sid;                // structure of atom i (same in input and cell-sorted order)
+    uint32_t *sid;                // structure of input atom i
+    uint32_t *sid_sorted;         // structure of the atom at cell-sorted position p
     uint32_t *cell_of, *rank_of;  // global cell index / arrival rank inside the cell (dead after the sort:
                                   // cell_of then holds the occlusion kernels' deferred-atom list)
     uint32_t *cells;              // counts, then exclusive starts (cell_capacity + 1 entries)
@@ -102,5 +111,6 @@ void launch_expand_frames(const float *xyz, const float *radius, const uint64_t 
 
 constexpr uint32_t kSegmentAtoms = 4096;  // atoms per bounds workgroup
 constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
+constexpr uint32_t kLdsCells = 73728;     // cells k_sort_small bins in LDS (16-bit counters, 144 KiB)
 
 }  // namespace rsasa

@@ -30,6 +30,8 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
         status->bad_input = 0;
         status->deferred = 0;
         status->total_cells = 0;
+        status->tail_cell_begin = 0;
+        status->tail_atom_base = 0;
     }
     if (s >= n_structures) return;
     const int pinf = f2ord(__int_as_float(0x7F800000)), ninf = f2ord(__int_as_float(0xFF800000));
@@ -37,6 +39,8 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
     a.min_x = a.min_y = a.min_z = pinf;   // spatial_grid.rs:113
     a.max_x = a.max_y = a.max_z = ninf;   // spatial_grid.rs:114
     a.max_r = f2ord(0.0f);                // fold(0.0f32, f32::max), lib.rs:262
+    a.n_atoms = 0;
+    a.first_atom = 0xFFFFFFFFu;
     a.pad = 0;
     acc[s] = a;
 }
@@ -72,19 +76,29 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         atomicMin(&a->min_z, f2ord(mnz)); atomicMax(&a->max_z, f2ord(mxz));
         atomicMax(&a->max_r, f2ord(mr));
     }
+    if (threadIdx.x == 0) {
+        atomicAdd(&b.acc[seg.sid].n_atoms, seg.end - seg.begin);
+        atomicMin(&b.acc[seg.sid].first_atom, seg.begin);
+    }
 }
 
 // SpatialGrid::new parameters (spatial_grid.rs:35-44 with cell_size from
-// lib.rs:76) for every structure, plus the exclusive scan of the cell counts
-// that places each structure's cells in the batch-wide cell array.
+// lib.rs:76) for every structure, plus the exclusive scans that place each
+// structure's cells in the batch-wide cell array and its atoms in the
+// cell-sorted arrays.  Structures whose cells fit the LDS (k_sort_small) come
+// first in both, in structure order; the others form the "tail" that the
+// batch-wide histogram / scan / scatter kernels handle.
 __global__ __launch_bounds__(1024) void k_finalize_grids(BatchView b)
 {
     __shared__ unsigned long long smem[16];
-    unsigned long long carry = 0;
+    __shared__ uint32_t smem32[16];
+    unsigned long long carry_s = 0, carry_l = 0;  // cells of LDS-binned / tail structures so far
+    uint32_t atoms_s = 0, atoms_l = 0;
     bool too_large = false, bad = false;
     for (uint32_t base = 0; base < b.n_structures; base += blockDim.x) {
         uint32_t s = base + threadIdx.x;
-        uint32_t ncells = 0;
+        uint32_t ncells = 0, na = 0;
+        bool in_lds = false;
         StructGrid g = {};
         if (s < b.n_structures) {
             StructAcc a = b.acc[s];
@@ -101,42 +115,135 @@ __global__ __launch_bounds__(1024) void k_finalize_grids(BatchView b)
             if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000))) { bad = true; nc = 1; d[0] = d[1] = d[2] = 1; }
             if (nc > 0x7FFFFFFFull) { too_large = true; nc = 1; d[0] = d[1] = d[2] = 1; }
             ncells = (uint32_t)nc;
+            na = a.n_atoms;
+            in_lds = ncells <= kLdsCells && na < 65536u;  // 16-bit counters and prefixes
             g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
             g.inv_cell = inv;
             g.dim_x = d[0]; g.dim_y = d[1]; g.dim_z = d[2];
             g.max_r = max_r;
             g.cell_size = cell;
             g.n_cells = ncells;
+            g.atom_begin = na ? a.first_atom : 0u;
+            g.n_atoms = na;
+            g.in_lds = in_lds ? 1u : 0u;
         }
-        // 64-bit scan: cell indices are 32-bit, so a batch is limited to 2^32 - 2 cells and
+        // 64-bit scans: cell indices are 32-bit, so a batch is limited to 2^32 - 2 cells and
         // anything beyond that is reported as an overflow of the workspace capacity.
-        unsigned long long total;
-        unsigned long long inc = block_incl_scan<16>((unsigned long long)ncells, smem, total);
+        unsigned long long total_s, total_l;
+        const unsigned long long inc_s = block_incl_scan<16>((unsigned long long)(in_lds ? ncells : 0u), smem, total_s);
+        __syncthreads();
+        const unsigned long long inc_l = block_incl_scan<16>((unsigned long long)(in_lds ? 0u : ncells), smem, total_l);
+        uint32_t tot_as, tot_al;
+        const uint32_t inc_as = block_incl_scan<16>(in_lds ? na : 0u, smem32, tot_as);
+        __syncthreads();
+        const uint32_t inc_al = block_incl_scan<16>(in_lds ? 0u : na, smem32, tot_al);
         if (s < b.n_structures) {
-            unsigned long long cb = carry + (inc - ncells);
+            // tail structures get the tail's own offsets here; its base is added below
+            const unsigned long long cb = in_lds ? carry_s + (inc_s - ncells) : carry_l + (inc_l - ncells);
             g.cell_base = (uint32_t)(cb > 0xFFFFFFFFull ? 0xFFFFFFFFull : cb);
+            g.sorted_base = in_lds ? atoms_s + (inc_as - na) : atoms_l + (inc_al - na);
             b.grids[s] = g;
         }
-        carry += total;
+        carry_s += total_s;
+        carry_l += total_l;
+        atoms_s += tot_as;
+        atoms_l += tot_al;
         __syncthreads();
+    }
+    // the tail starts on a 1024-cell boundary (vector accesses of the scan kernels) and leaves at
+    // least one entry after the LDS-binned cells for their end marker
+    const unsigned long long tail_begin = (carry_s + 1ull + 1023ull) & ~1023ull;
+    const unsigned long long total = tail_begin + carry_l;
+    for (uint32_t s = threadIdx.x; s < b.n_structures; s += blockDim.x) {
+        if (b.grids[s].in_lds) continue;
+        const unsigned long long cb = tail_begin + b.grids[s].cell_base;
+        b.grids[s].cell_base = (uint32_t)(cb > 0xFFFFFFFFull ? 0xFFFFFFFFull : cb);
+        b.grids[s].sorted_base += atoms_s;
     }
     too_large = __syncthreads_or(too_large);
     bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
-        b.status->total_cells = carry;
+        b.status->total_cells = total;
+        b.status->tail_cell_begin = tail_begin;
+        b.status->tail_atom_base = atoms_s;
         b.status->grid_too_large = too_large ? 1u : 0u;
         b.status->bad_input = bad ? 1u : 0u;
-        b.status->overflow = (carry > b.cell_capacity) ? 1u : 0u;
+        b.status->overflow = (total > b.cell_capacity || total > 0xFFFFFFF0ull) ? 1u : 0u;
     }
 }
+
+// Counting sort of ONE structure whose cells fit the LDS: 16-bit counters (two cells per word),
+// histogram with LDS atomics, in-place exclusive scan, then the cell starts and the sorted atoms
+// go to global memory.  Replaces k_zero_cells / k_cell_hist / k_scan_* / k_scatter for that
+// structure: the batch-wide cell array is written once and never read back.
+__global__ __launch_bounds__(1024) void k_sort_small(BatchView b)
+{
+    if (batch_aborted(b.status)) return;
+    __shared__ uint32_t s_cnt[kLdsCells / 2];
+    __shared__ uint32_t smem32[16];
+    const uint32_t s = blockIdx.x;
+    const StructGrid g = b.grids[s];
+    if (!g.in_lds) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_cells = g.n_cells, n_words = (n_cells + 1u) >> 1;
+    const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
+    for (uint32_t i = tid; i < n_words; i += 1024u) s_cnt[i] = 0u;
+    __syncthreads();
+    // spatial_grid.rs:53-62; the atomic's return value is the atom's slot inside its cell
+    for (uint32_t i = a0 + tid; i < a1; i += 1024u) {
+        uint32_t cx, cy, cz;
+        cell_coords(g, b.x[i], b.y[i], b.z[i], cx, cy, cz);
+        const uint32_t c = cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
+        const uint32_t sh = (c & 1u) * 16u;
+        const uint32_t old = atomicAdd(&s_cnt[c >> 1], 1u << sh);
+        b.cell_of[i] = c;
+        b.rank_of[i] = (old >> sh) & 0xFFFFu;
+    }
+    __syncthreads();
+    // exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive words
+    // (odd stride: no bank conflicts), sums them, the partial sums are scanned across the
+    // workgroup, and the words are rewritten as (prefix of the even cell | prefix of the odd one << 16)
+    const uint32_t per = ((n_words + 1023u) / 1024u) | 1u;
+    const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
+    uint32_t sum = 0;
+    for (uint32_t j = w0; j < w1; j++) {
+        const uint32_t v = s_cnt[j];
+        sum += (v & 0xFFFFu) + (v >> 16);
+    }
+    uint32_t total;
+    uint32_t running = block_incl_scan<16>(sum, smem32, total) - sum;
+    for (uint32_t j = w0; j < w1; j++) {
+        const uint32_t v = s_cnt[j];
+        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+        s_cnt[j] = running | ((running + lo) << 16);  // < 65536: the structure has < 65536 atoms
+        running += lo + hi;
+    }
+    __syncthreads();
+    // cell starts, plus the end marker that the last cell's run length is read from
+    for (uint32_t c = tid; c <= n_cells; c += 1024u) {
+        const uint32_t pre = c < n_cells ? (s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : g.n_atoms;
+        b.cells[g.cell_base + c] = g.sorted_base + pre;
+    }
+    // scatter (spatial_grid.rs:70-93)
+    for (uint32_t i = a0 + tid; i < a1; i += 1024u) {
+        const uint32_t c = b.cell_of[i];
+        const uint32_t pos = g.sorted_base + ((s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu) + b.rank_of[i];
+        b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
+        b.sorted_orig[pos] = i;
+        b.sid_sorted[pos] = s;
+        if (b.id) b.sorted_id[pos] = b.id[i];
+    }
+}
+
+// ---- batch-wide path for the structures of the tail (cells do not fit the LDS) ----
 
 __global__ __launch_bounds__(256) void k_zero_cells(BatchView b)
 {
     if (batch_aborted(b.status)) return;
-    // + end sentinel, rounded up to whole 16-byte vectors (the buffer has the slack)
+    // tail cells + end sentinel, rounded up to whole 16-byte vectors (the buffer has the slack)
     const uint64_t n4 = (b.status->total_cells + 1 + 3) / 4;
     uint4 *c4 = reinterpret_cast<uint4 *>(b.cells);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+    for (uint64_t i = b.status->tail_cell_begin / 4 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (uint64_t)gridDim.x * blockDim.x)
         c4[i] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -149,6 +256,7 @@ __global__ __launch_bounds__(256) void k_cell_hist(BatchView b)
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n_atoms) return;
     const StructGrid g = b.grids[b.sid[i]];
+    if (g.in_lds) return;
     uint32_t cx, cy, cz;
     cell_coords(g, b.x[i], b.y[i], b.z[i], cx, cy, cz);
     uint32_t cell = g.cell_base + cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
@@ -160,13 +268,14 @@ __global__ __launch_bounds__(256) void k_cell_hist(BatchView b)
 // phases over a fixed grid of kScanBlocks workgroups.
 __device__ __forceinline__ void scan_range(const BatchView &b, uint64_t &begin, uint64_t &end)
 {
-    const uint64_t n = b.status->total_cells + 1;
-    uint64_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
+    const uint64_t first = b.status->tail_cell_begin;  // multiple of 1024
+    const uint64_t last = b.status->total_cells + 1;   // tail cells + end sentinel
+    uint64_t chunk = (last - first + kScanBlocks - 1) / kScanBlocks;
     chunk = (chunk + 1023) & ~uint64_t(1023);
-    begin = (uint64_t)blockIdx.x * chunk;
-    if (begin > n) begin = n;
+    begin = first + (uint64_t)blockIdx.x * chunk;
+    if (begin > last) begin = last;
     end = begin + chunk;
-    if (end > n) end = n;
+    if (end > last) end = last;
 }
 
 __global__ __launch_bounds__(256) void k_scan_reduce(BatchView b)
@@ -204,7 +313,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(BatchView b)
     __shared__ uint32_t smem[4];
     uint64_t begin, end;
     scan_range(b, begin, end);
-    uint32_t running = b.scan_block_sums[blockIdx.x];
+    uint32_t running = b.status->tail_atom_base + b.scan_block_sums[blockIdx.x];
     uint4 *c4 = reinterpret_cast<uint4 *>(b.cells);
     for (uint64_t tile = begin; tile < end; tile += 1024) {
         const uint64_t i0 = tile + (uint64_t)threadIdx.x * 4;
@@ -227,9 +336,12 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
     if (batch_aborted(b.status)) return;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n_atoms) return;
+    const uint32_t s = b.sid[i];
+    if (b.grids[s].in_lds) return;
     uint32_t pos = b.cells[b.cell_of[i]] + b.rank_of[i];
     b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
     b.sorted_orig[pos] = i;
+    b.sid_sorted[pos] = s;
     if (b.id) b.sorted_id[pos] = b.id[i];
 }
 
@@ -255,6 +367,8 @@ void launch_grid_build(const BatchView &b, hipStream_t stream)
     if (b.n_segments)
         hipLaunchKernelGGL(k_bounds, dim3(b.n_segments), dim3(256), 0, stream, b);
     hipLaunchKernelGGL(k_finalize_grids, dim3(1), dim3(1024), 0, stream, b);
+    if (b.n_structures)
+        hipLaunchKernelGGL(k_sort_small, dim3(b.n_structures), dim3(1024), 0, stream, b);
     hipLaunchKernelGGL(k_zero_cells, dim3(2048), dim3(256), 0, stream, b);
     if (b.n_atoms)
         hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);
