@@ -61,6 +61,11 @@ struct Lattice {
                              // the rest the scalar remainder rule (lib.rs:185-186,206-207)
 };
 
+// Running sums of the grid placement scan: (cells, atoms) of the LDS-binned / tail structures.
+struct GridSums {
+    unsigned long long cells_s, cells_l, atoms_s, atoms_l;
+};
+
 // Everything a batch run needs on the device.  All pointers are device pointers.
 struct BatchView {
     // inputs
@@ -80,6 +85,7 @@ struct BatchView {
     uint32_t *cells;              // counts, then exclusive starts (cell_capacity + 1 entries)
     uint64_t cell_capacity;
     uint32_t *scan_block_sums;
+    GridSums *grid_sums;   // per 256 structures: (cells, atoms) x (LDS-binned, tail), 4 x u64
     float4 *sorted_xyzr;          // cell-sorted (x, y, z, radius)
     uint32_t *sorted_orig;        // cell-sorted position -> input index
     uint64_t *sorted_id;          // cell-sorted ids (only when id != null)

@@ -1,7 +1,7 @@
 // HIP kernels of the MI355X-native Shrake-Rupley engine (gfx950 / CDNA4 only).
 //
 // Pipeline for one batch of independent structures (all on one stream):
-//   k_init_acc -> k_bounds -> k_finalize_grids            per-structure cell grids
+//   k_init_acc -> k_bounds -> k_grid_params/scan/bases    per-structure cell grids
 //   k_zero_cells -> k_cell_hist -> k_scan_* -> k_scatter  counting sort into cells
 //   k_occlusion                                           candidate gather + point tests
 //   k_residue_sums                                        ResidueLevel aggregation
@@ -82,93 +82,139 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     }
 }
 
-// SpatialGrid::new parameters (spatial_grid.rs:35-44 with cell_size from
-// lib.rs:76) for every structure, plus the exclusive scans that place each
-// structure's cells in the batch-wide cell array and its atoms in the
-// cell-sorted arrays.  Structures whose cells fit the LDS (k_sort_small) come
-// first in both, in structure order; the others form the "tail" that the
-// batch-wide histogram / scan / scatter kernels handle.
-__global__ __launch_bounds__(1024) void k_finalize_grids(BatchView b)
+// SpatialGrid::new parameters (spatial_grid.rs:35-44 with cell_size from lib.rs:76).
+__device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe, bool &bad, bool &too_large)
 {
-    __shared__ unsigned long long smem[16];
-    __shared__ uint32_t smem32[16];
-    unsigned long long carry_s = 0, carry_l = 0;  // cells of LDS-binned / tail structures so far
-    uint32_t atoms_s = 0, atoms_l = 0;
-    bool too_large = false, bad = false;
-    for (uint32_t base = 0; base < b.n_structures; base += blockDim.x) {
-        uint32_t s = base + threadIdx.x;
-        uint32_t ncells = 0, na = 0;
-        bool in_lds = false;
-        StructGrid g = {};
-        if (s < b.n_structures) {
-            StructAcc a = b.acc[s];
-            float max_r = ord2f(a.max_r);
-            float cell = b.probe + max_r;                                  // lib.rs:76
-            float inv = 1.0f / cell;                                       // spatial_grid.rs:36
-            float mn[3] = {ord2f(a.min_x) - cell, ord2f(a.min_y) - cell, ord2f(a.min_z) - cell};
-            float mx[3] = {ord2f(a.max_x) + cell, ord2f(a.max_y) + cell, ord2f(a.max_z) + cell};
-            uint32_t d[3];
+    StructGrid g = {};
+    float max_r = ord2f(a.max_r);
+    float cell = probe + max_r;                                    // lib.rs:76
+    float inv = 1.0f / cell;                                       // spatial_grid.rs:36
+    float mn[3] = {ord2f(a.min_x) - cell, ord2f(a.min_y) - cell, ord2f(a.min_z) - cell};
+    float mx[3] = {ord2f(a.max_x) + cell, ord2f(a.max_y) + cell, ord2f(a.max_z) + cell};
+    uint32_t d[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++)                                    // spatial_grid.rs:39-43
-                d[k] = f2u_sat(ceilf((mx[k] - mn[k]) * inv)) + 1u;
-            unsigned long long nc = (unsigned long long)d[0] * d[1] * d[2];
-            if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000))) { bad = true; nc = 1; d[0] = d[1] = d[2] = 1; }
-            if (nc > 0x7FFFFFFFull) { too_large = true; nc = 1; d[0] = d[1] = d[2] = 1; }
-            ncells = (uint32_t)nc;
-            na = a.n_atoms;
-            in_lds = ncells <= kLdsCells && na < 65536u;  // 16-bit counters and prefixes
-            g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
-            g.inv_cell = inv;
-            g.dim_x = d[0]; g.dim_y = d[1]; g.dim_z = d[2];
-            g.max_r = max_r;
-            g.cell_size = cell;
-            g.n_cells = ncells;
-            g.atom_begin = na ? a.first_atom : 0u;
-            g.n_atoms = na;
-            g.in_lds = in_lds ? 1u : 0u;
+    for (int k = 0; k < 3; k++)                                    // spatial_grid.rs:39-43
+        d[k] = f2u_sat(ceilf((mx[k] - mn[k]) * inv)) + 1u;
+    unsigned long long nc = (unsigned long long)d[0] * d[1] * d[2];
+    if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000))) { bad = true; nc = 1; d[0] = d[1] = d[2] = 1; }
+    if (nc > 0x7FFFFFFFull) { too_large = true; nc = 1; d[0] = d[1] = d[2] = 1; }
+    g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
+    g.inv_cell = inv;
+    g.dim_x = d[0]; g.dim_y = d[1]; g.dim_z = d[2];
+    g.max_r = max_r;
+    g.cell_size = cell;
+    g.n_cells = (uint32_t)nc;
+    g.atom_begin = a.n_atoms ? a.first_atom : 0u;
+    g.n_atoms = a.n_atoms;
+    // 16-bit LDS counters and prefixes: two LDS tiers (k_sort_small), else the batch-wide kernels
+    g.in_lds = a.n_atoms >= 65536u ? 0u : (g.n_cells <= kLdsCells / 2 ? 1u : (g.n_cells <= kLdsCells ? 2u : 0u));
+    return g;
+}
+
+// Grids of all structures plus the exclusive scans that place each structure's cells in the
+// batch-wide cell array and its atoms in the cell-sorted arrays.  Structures whose cells fit the
+// LDS (k_sort_small) come first in both, in structure order; the others form the "tail" that the
+// batch-wide histogram / scan / scatter kernels handle.  Three small kernels:
+//   k_grid_params  (one thread per structure)  grid + per-workgroup sums of (cells, atoms) x (LDS, tail)
+//   k_grid_scan    (one workgroup)             exclusive scan of those sums, totals -> BatchStatus
+//   k_grid_bases   (one thread per structure)  cell_base / sorted_base of every structure
+// inclusive scan of four running sums over a workgroup of NW waves; returns the workgroup totals
+template <int NW>
+__device__ __forceinline__ GridSums block_scan_sums(GridSums &v, unsigned long long (*part)[4])
+{
+    const uint32_t l = lane_id(), wv = threadIdx.x / kWave;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const unsigned long long t0 = __shfl_up(v.cells_s, d, kWave), t1 = __shfl_up(v.cells_l, d, kWave);
+        const unsigned long long t2 = __shfl_up(v.atoms_s, d, kWave), t3 = __shfl_up(v.atoms_l, d, kWave);
+        if (l >= (uint32_t)d) { v.cells_s += t0; v.cells_l += t1; v.atoms_s += t2; v.atoms_l += t3; }
+    }
+    __syncthreads();
+    if (l == kWave - 1) { part[wv][0] = v.cells_s; part[wv][1] = v.cells_l; part[wv][2] = v.atoms_s; part[wv][3] = v.atoms_l; }
+    __syncthreads();
+    unsigned long long off[4] = {0, 0, 0, 0}, tot[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long x = part[i][k];
+            if ((uint32_t)i < wv) off[k] += x;
+            tot[k] += x;
         }
-        // 64-bit scans: cell indices are 32-bit, so a batch is limited to 2^32 - 2 cells and
-        // anything beyond that is reported as an overflow of the workspace capacity.
-        unsigned long long total_s, total_l;
-        const unsigned long long inc_s = block_incl_scan<16>((unsigned long long)(in_lds ? ncells : 0u), smem, total_s);
-        __syncthreads();
-        const unsigned long long inc_l = block_incl_scan<16>((unsigned long long)(in_lds ? 0u : ncells), smem, total_l);
-        uint32_t tot_as, tot_al;
-        const uint32_t inc_as = block_incl_scan<16>(in_lds ? na : 0u, smem32, tot_as);
-        __syncthreads();
-        const uint32_t inc_al = block_incl_scan<16>(in_lds ? 0u : na, smem32, tot_al);
-        if (s < b.n_structures) {
-            // tail structures get the tail's own offsets here; its base is added below
-            const unsigned long long cb = in_lds ? carry_s + (inc_s - ncells) : carry_l + (inc_l - ncells);
-            g.cell_base = (uint32_t)(cb > 0xFFFFFFFFull ? 0xFFFFFFFFull : cb);
-            g.sorted_base = in_lds ? atoms_s + (inc_as - na) : atoms_l + (inc_al - na);
-            b.grids[s] = g;
-        }
-        carry_s += total_s;
-        carry_l += total_l;
-        atoms_s += tot_as;
-        atoms_l += tot_al;
+    }
+    v.cells_s += off[0]; v.cells_l += off[1]; v.atoms_s += off[2]; v.atoms_l += off[3];
+    return GridSums{tot[0], tot[1], tot[2], tot[3]};
+}
+
+__global__ __launch_bounds__(256) void k_grid_params(BatchView b)
+{
+    __shared__ unsigned long long part[4][4];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    GridSums v = {0, 0, 0, 0};
+    if (s < b.n_structures) {
+        bool bad = false, too_large = false;
+        const StructGrid g = make_grid(b.acc[s], b.probe, bad, too_large);
+        b.grids[s] = g;  // cell_base / sorted_base follow in k_grid_bases
+        if (bad) b.status->bad_input = 1u;
+        if (too_large) b.status->grid_too_large = 1u;
+        if (g.in_lds) { v.cells_s = g.n_cells; v.atoms_s = g.n_atoms; }
+        else { v.cells_l = g.n_cells; v.atoms_l = g.n_atoms; }
+    }
+    const GridSums tot = block_scan_sums<4>(v, part);
+    if (threadIdx.x == 0) b.grid_sums[blockIdx.x] = tot;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * kWave) void k_grid_scan(BatchView b, uint32_t n_parts)
+{
+    __shared__ unsigned long long part[NW][4];
+    GridSums carry = {0, 0, 0, 0};
+    for (uint32_t base = 0; base < n_parts; base += blockDim.x) {
+        const uint32_t i = base + threadIdx.x;
+        GridSums mine = {0, 0, 0, 0};
+        if (i < n_parts) mine = b.grid_sums[i];
+        GridSums v = mine;
+        const GridSums tot = block_scan_sums<NW>(v, part);
+        if (i < n_parts)
+            b.grid_sums[i] = GridSums{carry.cells_s + v.cells_s - mine.cells_s, carry.cells_l + v.cells_l - mine.cells_l,
+                                      carry.atoms_s + v.atoms_s - mine.atoms_s, carry.atoms_l + v.atoms_l - mine.atoms_l};
+        carry.cells_s += tot.cells_s; carry.cells_l += tot.cells_l;
+        carry.atoms_s += tot.atoms_s; carry.atoms_l += tot.atoms_l;
         __syncthreads();
     }
-    // the tail starts on a 1024-cell boundary (vector accesses of the scan kernels) and leaves at
-    // least one entry after the LDS-binned cells for their end marker
-    const unsigned long long tail_begin = (carry_s + 1ull + 1023ull) & ~1023ull;
-    const unsigned long long total = tail_begin + carry_l;
-    for (uint32_t s = threadIdx.x; s < b.n_structures; s += blockDim.x) {
-        if (b.grids[s].in_lds) continue;
-        const unsigned long long cb = tail_begin + b.grids[s].cell_base;
-        b.grids[s].cell_base = (uint32_t)(cb > 0xFFFFFFFFull ? 0xFFFFFFFFull : cb);
-        b.grids[s].sorted_base += atoms_s;
-    }
-    too_large = __syncthreads_or(too_large);
-    bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
+        // the tail starts on a 1024-cell boundary (vector accesses of the scan kernels) and leaves
+        // at least one entry after the LDS-binned cells for their end marker.  Cell indices are
+        // 32-bit: a batch is limited to 2^32 - 16 cells, more is reported as an overflow.
+        const unsigned long long tail_begin = (carry.cells_s + 1ull + 1023ull) & ~1023ull;
+        const unsigned long long total = tail_begin + carry.cells_l;
         b.status->total_cells = total;
         b.status->tail_cell_begin = tail_begin;
-        b.status->tail_atom_base = atoms_s;
-        b.status->grid_too_large = too_large ? 1u : 0u;
-        b.status->bad_input = bad ? 1u : 0u;
+        b.status->tail_atom_base = (uint32_t)carry.atoms_s;
         b.status->overflow = (total > b.cell_capacity || total > 0xFFFFFFF0ull) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
+{
+    __shared__ unsigned long long part[4][4];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ncells = 0, na = 0;
+    bool in_lds = false;
+    if (s < b.n_structures) {
+        ncells = b.grids[s].n_cells;
+        na = b.grids[s].n_atoms;
+        in_lds = b.grids[s].in_lds != 0u;
+    }
+    GridSums v = {in_lds ? ncells : 0u, in_lds ? 0u : ncells, in_lds ? na : 0u, in_lds ? 0u : na};
+    (void)block_scan_sums<4>(v, part);
+    if (s < b.n_structures) {
+        const GridSums base = b.grid_sums[blockIdx.x];
+        const unsigned long long cb = in_lds ? base.cells_s + v.cells_s - ncells
+                                             : b.status->tail_cell_begin + base.cells_l + v.cells_l - ncells;
+        b.grids[s].cell_base = (uint32_t)(cb > 0xFFFFFFFFull ? 0xFFFFFFFFull : cb);
+        b.grids[s].sorted_base = (uint32_t)(in_lds ? base.atoms_s + v.atoms_s - na
+                                                   : b.status->tail_atom_base + base.atoms_l + v.atoms_l - na);
     }
 }
 
@@ -176,28 +222,50 @@ __global__ __launch_bounds__(1024) void k_finalize_grids(BatchView b)
 // histogram with LDS atomics, in-place exclusive scan, then the cell starts and the sorted atoms
 // go to global memory.  Replaces k_zero_cells / k_cell_hist / k_scan_* / k_scatter for that
 // structure: the batch-wide cell array is written once and never read back.
+template <uint32_t TIER>  // 1: up to kLdsCells / 2 cells (two workgroups per CU), 2: up to kLdsCells
 __global__ __launch_bounds__(1024) void k_sort_small(BatchView b)
 {
     if (batch_aborted(b.status)) return;
-    __shared__ uint32_t s_cnt[kLdsCells / 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kLdsCells / (TIER == 1 ? 4 : 2)];
     __shared__ uint32_t smem32[16];
     const uint32_t s = blockIdx.x;
     const StructGrid g = b.grids[s];
-    if (!g.in_lds) return;
+    if (g.in_lds != TIER) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_cells = g.n_cells, n_words = (n_cells + 1u) >> 1;
     const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
-    for (uint32_t i = tid; i < n_words; i += 1024u) s_cnt[i] = 0u;
+    {
+        uint4 *z4 = reinterpret_cast<uint4 *>(s_cnt);
+        for (uint32_t i = tid; i < (n_words + 3u) / 4u; i += 1024u) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
-    // spatial_grid.rs:53-62; the atomic's return value is the atom's slot inside its cell
-    for (uint32_t i = a0 + tid; i < a1; i += 1024u) {
-        uint32_t cx, cy, cz;
-        cell_coords(g, b.x[i], b.y[i], b.z[i], cx, cy, cz);
-        const uint32_t c = cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
-        const uint32_t sh = (c & 1u) * 16u;
-        const uint32_t old = atomicAdd(&s_cnt[c >> 1], 1u << sh);
-        b.cell_of[i] = c;
-        b.rank_of[i] = (old >> sh) & 0xFFFFu;
+    // spatial_grid.rs:53-62; the atomic's return value is the atom's slot inside its cell.
+    // Four atoms per trip, loads first: one workgroup per CU has little else to hide latency with.
+    const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z, *__restrict__ pr = b.radius;
+    uint32_t *__restrict__ cell_of = b.cell_of, *__restrict__ rank_of = b.rank_of;
+    for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+        }
+        uint32_t c[4], old[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t cx, cy, cz;
+            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+            c[k] = cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
+            if (i0 + 1024u * k < a1) old[k] = atomicAdd(&s_cnt[c[k] >> 1], 1u << ((c[k] & 1u) * 16u));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + 1024u * k;
+            if (i < a1) {
+                cell_of[i] = c[k];
+                rank_of[i] = (old[k] >> ((c[k] & 1u) * 16u)) & 0xFFFFu;
+            }
+        }
     }
     __syncthreads();
     // exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive words
@@ -224,14 +292,30 @@ __global__ __launch_bounds__(1024) void k_sort_small(BatchView b)
         const uint32_t pre = c < n_cells ? (s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : g.n_atoms;
         b.cells[g.cell_base + c] = g.sorted_base + pre;
     }
-    // scatter (spatial_grid.rs:70-93)
-    for (uint32_t i = a0 + tid; i < a1; i += 1024u) {
-        const uint32_t c = b.cell_of[i];
-        const uint32_t pos = g.sorted_base + ((s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu) + b.rank_of[i];
-        b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
-        b.sorted_orig[pos] = i;
-        b.sid_sorted[pos] = s;
-        if (b.id) b.sorted_id[pos] = b.id[i];
+    // scatter (spatial_grid.rs:70-93), four atoms per trip
+    const uint64_t *__restrict__ pid = b.id;
+    for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
+        uint32_t c[4], rk[4];
+        float4 v[4];
+        uint64_t id[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+            c[k] = cell_of[i]; rk[k] = rank_of[i];
+            v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
+            id[k] = pid ? pid[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + 1024u * k;
+            if (i < a1) {
+                const uint32_t pos = g.sorted_base + ((s_cnt[c[k] >> 1] >> ((c[k] & 1u) * 16u)) & 0xFFFFu) + rk[k];
+                b.sorted_xyzr[pos] = v[k];
+                b.sorted_orig[pos] = i;
+                b.sid_sorted[pos] = s;
+                if (pid) b.sorted_id[pos] = id[k];
+            }
+        }
     }
 }
 
@@ -366,9 +450,15 @@ void launch_grid_build(const BatchView &b, hipStream_t stream)
                        b.acc, b.n_structures, b.status);
     if (b.n_segments)
         hipLaunchKernelGGL(k_bounds, dim3(b.n_segments), dim3(256), 0, stream, b);
-    hipLaunchKernelGGL(k_finalize_grids, dim3(1), dim3(1024), 0, stream, b);
-    if (b.n_structures)
-        hipLaunchKernelGGL(k_sort_small, dim3(b.n_structures), dim3(1024), 0, stream, b);
+    const uint32_t n_parts = cdiv(b.n_structures > 0 ? b.n_structures : 1, 256);
+    hipLaunchKernelGGL(k_grid_params, dim3(n_parts), dim3(256), 0, stream, b);
+    if (n_parts <= 256) hipLaunchKernelGGL(k_grid_scan<1>, dim3(1), dim3(64), 0, stream, b, n_parts);
+    else hipLaunchKernelGGL(k_grid_scan<16>, dim3(1), dim3(1024), 0, stream, b, n_parts);
+    hipLaunchKernelGGL(k_grid_bases, dim3(n_parts), dim3(256), 0, stream, b);
+    if (b.n_structures) {
+        hipLaunchKernelGGL(k_sort_small<1>, dim3(b.n_structures), dim3(1024), 0, stream, b);
+        hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
+    }
     hipLaunchKernelGGL(k_zero_cells, dim3(2048), dim3(256), 0, stream, b);
     if (b.n_atoms)
         hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);

@@ -435,3 +435,44 @@ def test_fast_kernel_defers_dense_atoms_inside_a_mixed_batch(ctx):
                                               PROBE, 100, 8, return_details=True)
     assert np.array_equal(k[-n_blob:], k_blob)
     assert k_blob.max() > 160
+
+
+def test_grid_build_paths_mixed(ctx):
+    """Cell binning has three routes: one workgroup per structure with 16-bit LDS counters (two
+    size tiers), and the batch-wide histogram / scan / scatter for structures with more than
+    73 728 cells or 65 535 atoms.  One batch with all of them, interleaved, plus empty structures."""
+    rng = np.random.default_rng(17)
+    parts = []
+    # tier 1 (compact), tier 2 (elongated: ~50 k cells), tail by cells (very elongated), tail by atoms
+    parts.append(rng.uniform(0, 30, size=(900, 3)))
+    parts.append(rng.uniform(0, 1, size=(700, 3)) * np.array([900.0, 40.0, 40.0]))
+    parts.append(np.zeros((0, 3)))
+    parts.append(rng.uniform(0, 1, size=(800, 3)) * np.array([2500.0, 45.0, 45.0]))
+    parts.append(rng.uniform(0, 25, size=(500, 3)))
+    parts.append(rng.uniform(0, 95, size=(70000, 3)))
+    parts.append(np.zeros((0, 3)))
+    parts.append(rng.uniform(0, 20, size=(300, 3)))
+    xyz = np.concatenate(parts).astype(np.float32)
+    so = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint32)
+    r = rng.uniform(1.2, 2.0, len(xyz)).astype(np.float32)
+    ids = np.arange(len(xyz), dtype=np.uint64)
+    b = bw.Batch(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), r, ids, so, so)
+    atom, _, k = _device_run(ctx, b, want_res=False)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, so, PROBE, 100, 8, threads=8)
+    assert np.array_equal(atom, want)
+
+
+def test_many_tiny_structures(ctx):
+    """70 000 structures of 1-3 atoms: the grid placement scan runs over several chunks of
+    per-workgroup sums, every structure is its own LDS-binned grid."""
+    rng = np.random.default_rng(23)
+    counts = rng.integers(1, 4, 70000)
+    so = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+    n = int(so[-1])
+    xyz = rng.uniform(0, 4, size=(n, 3)).astype(np.float32)
+    r = rng.uniform(1.2, 2.0, n).astype(np.float32)
+    ids = np.arange(n, dtype=np.uint64)
+    b = bw.Batch(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), r, ids, so, so)
+    atom, _, _ = _device_run(ctx, b, want_res=False)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, so, PROBE, 100, 8, threads=8)
+    assert np.array_equal(atom, want)
