@@ -35,7 +35,7 @@ def test_struct_layouts_match_header():
     assert _capi.ATOM_DTYPE.itemsize == 24
     assert _capi.ATOM_DTYPE.fields["radius"][1] == 12 and _capi.ATOM_DTYPE.fields["id"][1] == 16
     assert C.sizeof(_capi.DeviceBatch) == 13 * 8
-    assert C.sizeof(_capi.Timings) == 32
+    assert C.sizeof(_capi.Timings) == 40
 
 
 def test_status_strings():
