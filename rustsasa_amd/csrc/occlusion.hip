@@ -60,6 +60,21 @@ void launch_v0(const OccArgs &a, hipStream_t stream)
     else hipLaunchKernelGGL((k_occlusion_v0<NCH, false>), dim3(a.n_blocks), dim3(256), 0, stream, a);
 }
 
+template <bool HAS_ID, bool HAS_REM>
+void launch_fast2(bool half1, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
+{
+    if (half1) hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, true>), dim3(n_blocks), dim3(256), 0, stream, a3);
+    else hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+}
+
+void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
+{
+    if (has_id && rem) launch_fast2<true, true>(half1, n_blocks, stream, a3);
+    else if (has_id) launch_fast2<true, false>(half1, n_blocks, stream, a3);
+    else if (rem) launch_fast2<false, true>(half1, n_blocks, stream, a3);
+    else launch_fast2<false, false>(half1, n_blocks, stream, a3);
+}
+
 }  // namespace
 
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
@@ -96,10 +111,8 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         a3.work_list_out = b.cell_of;  // dead since k_scatter
         a3.work_count_out = &b.status->deferred;
         const bool rem = lat.n_points != lat.n_fused;
-        if (b.id && rem) hipLaunchKernelGGL((k_occlusion_fast<true, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
-        else if (b.id) hipLaunchKernelGGL((k_occlusion_fast<true, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
-        else if (rem) hipLaunchKernelGGL((k_occlusion_fast<false, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
-        else hipLaunchKernelGGL((k_occlusion_fast<false, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
+        const bool half1 = lat.n_fused <= 96u;  // the second chunk's fused points fit half a wave
+        launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         a3.work_list = b.cell_of;
         a3.work_count = &b.status->deferred;
         a3.atoms_per_wave = 1;
