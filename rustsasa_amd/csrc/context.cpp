@@ -73,11 +73,15 @@ struct rsasa_context {
     int simd_width = 8;
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool overlap_tail = false;                    // RSASA_OVERLAP_TAIL=1: bin the tail on the side stream, next to the first
+                                                  // occlusion launch (measured: step -2.5 %, occlusion kernels +5 % from contention)
+    hipStream_t side_stream = nullptr;            // runs the tail's binning next to the launch stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     rsasa_timings_t timings{};
     bool timings_valid = false;
 
     // workspace (device)
-    DeviceBuffer segments, acc, grids, grid_sums, sid, sid_sorted, cell_of, rank_of, cells, scan_sums, sorted_xyzr,
+    DeviceBuffer segments, acc, grids, grid_sums, sid, sid_sorted, deferred_list, cell_of, rank_of, cells, scan_sums, sorted_xyzr,
         sorted_orig, sorted_id, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
@@ -230,6 +234,7 @@ int enqueue_pending(rsasa_context *ctx)
     if ((rc = reserve(ctx, ctx->grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
     if ((rc = reserve(ctx, ctx->sid, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rank_of, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1) * 4))) return rc;
@@ -256,6 +261,7 @@ int enqueue_pending(rsasa_context *ctx)
     v.grid_sums = (GridSums *)ctx->grid_sums.p;
     v.sid = (uint32_t *)ctx->sid.p;
     v.sid_sorted = (uint32_t *)ctx->sid_sorted.p;
+    v.deferred_list = (uint32_t *)ctx->deferred_list.p;
     v.cell_of = (uint32_t *)ctx->cell_of.p;
     v.rank_of = (uint32_t *)ctx->rank_of.p;
     v.cells = (uint32_t *)ctx->cells.p;
@@ -269,10 +275,30 @@ int enqueue_pending(rsasa_context *ctx)
     v.residue_sasa = (R && bt.residue_offsets) ? bt.out_residue_sasa : nullptr;
     v.neighbor_counts = bt.out_neighbor_counts;
 
+    // Launch stream: grids -> LDS binning -> occlusion of the LDS-binned structures -> (join) ->
+    // occlusion of the tail -> sums.  Side stream (forked after the LDS binning): the tail's
+    // batch-wide binning, which is bandwidth bound and runs next to the compute-bound occlusion kernel.
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
-    launch_grid_build(v, st);
-    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-    launch_occlusion(v, lat, ctx->tuning, st);
+    launch_grid_prepare(v, st);
+    const bool overlap = ctx->overlap_tail;
+    if (overlap) {
+        launch_sort_lds(v, st);
+        // fork here, not before the LDS binning: two bandwidth-bound phases gain nothing from
+        // running side by side, the occlusion kernel (compute bound) hides the tail's binning
+        RS_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+        RS_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+        launch_sort_tail(v, ctx->side_stream);
+        RS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        launch_occlusion(v, lat, ctx->tuning, kOccHead, st);
+        RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+        launch_occlusion(v, lat, ctx->tuning, kOccRest, st);
+    } else {
+        launch_sort_lds(v, st);
+        launch_sort_tail(v, st);
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
+    }
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     launch_residue_sums(v, st);
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
@@ -395,6 +421,9 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&ctx->h_status, sizeof(BatchStatus), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -405,6 +434,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     if (const char *v = std::getenv("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
     if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
     if (const char *v = std::getenv("RSASA_DEBUG_STOP")) ctx->tuning.debug_stop = (uint32_t)std::atoi(v);
+    if (const char *v = std::getenv("RSASA_OVERLAP_TAIL")) ctx->overlap_tail = std::atoi(v) != 0;
     *out_ctx = ctx;
     return RSASA_OK;
 }
@@ -414,7 +444,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (!ctx) return RSASA_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid, &ctx->sid_sorted, &ctx->cell_of,
+    for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
@@ -427,6 +457,9 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < 4; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RSASA_OK;

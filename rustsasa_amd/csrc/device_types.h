@@ -46,7 +46,7 @@ struct BatchStatus {
     uint32_t overflow;        // total cells exceed the workspace capacity: re-run after growing
     uint32_t grid_too_large;  // some structure needs more than 2^31 cells
     uint32_t bad_input;       // probe + max_r <= 0 or non-finite bounds
-    uint32_t deferred;        // atoms k_occlusion_fast left to the general kernel (list in cell_of)
+    uint32_t deferred;        // atoms k_occlusion_fast left to the general kernel (BatchView::deferred_list)
     uint64_t total_cells;     // cells of the batch-wide array in use (LDS-binned structures first, then the tail)
     uint64_t tail_cell_begin; // first cell of the structures binned by the batch-wide kernels (multiple of 1024)
     uint32_t tail_atom_base;  // their first position in the cell-sorted arrays (= atoms of the LDS-binned structures)
@@ -80,8 +80,8 @@ struct BatchView {
     StructGrid *grids;
     uint32_t *sid;                // structure of input atom i
     uint32_t *sid_sorted;         // structure of the atom at cell-sorted position p
-    uint32_t *cell_of, *rank_of;  // global cell index / arrival rank inside the cell (dead after the sort:
-                                  // cell_of then holds the occlusion kernels' deferred-atom list)
+    uint32_t *cell_of, *rank_of;  // cell index / arrival rank inside the cell (binning only)
+    uint32_t *deferred_list;      // atoms k_occlusion_fast left to the general kernel (BatchStatus::deferred entries)
     uint32_t *cells;              // counts, then exclusive starts (cell_capacity + 1 entries)
     uint64_t cell_capacity;
     uint32_t *scan_block_sums;
@@ -106,9 +106,18 @@ struct OcclusionTuning {
 };
 
 // Launchers implemented in kernels.hip / occlusion.hip.  Each only enqueues on `stream`.
-void launch_grid_build(const BatchView &b, hipStream_t stream);
+void launch_grid_prepare(const BatchView &b, hipStream_t stream);
+void launch_sort_lds(const BatchView &b, hipStream_t stream);
+void launch_sort_tail(const BatchView &b, hipStream_t stream);
+// Which atoms (cell-sorted positions) an occlusion launch covers: the tail's binning may still be
+// running on another stream while the LDS-binned structures are processed.
+enum OcclusionPart : uint32_t {
+    kOccAll = 0,   // every atom (both binning routes are complete)
+    kOccHead = 1,  // positions below BatchStatus::tail_atom_base (LDS-binned structures); may launch nothing
+    kOccRest = 2,  // whatever kOccHead did not launch, plus the deferred atoms
+};
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
-                      hipStream_t stream);
+                      OcclusionPart part, hipStream_t stream);
 void launch_residue_sums(const BatchView &b, hipStream_t stream);
 void launch_expand_frames(const float *xyz, const float *radius, const uint64_t *id,
                           const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t n_res,

@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void k_residue_sums(BatchView b)
 
 }  // namespace
 
-void launch_grid_build(const BatchView &b, hipStream_t stream)
+// Grid parameters and placement of every structure (everything the two binning routes need).
+void launch_grid_prepare(const BatchView &b, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_init_acc, dim3(cdiv(b.n_structures > 0 ? b.n_structures : 1, 256)), dim3(256), 0, stream,
                        b.acc, b.n_structures, b.status);
@@ -455,10 +456,20 @@ void launch_grid_build(const BatchView &b, hipStream_t stream)
     if (n_parts <= 256) hipLaunchKernelGGL(k_grid_scan<1>, dim3(1), dim3(64), 0, stream, b, n_parts);
     else hipLaunchKernelGGL(k_grid_scan<16>, dim3(1), dim3(1024), 0, stream, b, n_parts);
     hipLaunchKernelGGL(k_grid_bases, dim3(n_parts), dim3(256), 0, stream, b);
-    if (b.n_structures) {
-        hipLaunchKernelGGL(k_sort_small<1>, dim3(b.n_structures), dim3(1024), 0, stream, b);
-        hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
-    }
+}
+
+// Binning of the structures whose grid fits the LDS (one workgroup each).
+void launch_sort_lds(const BatchView &b, hipStream_t stream)
+{
+    if (!b.n_structures) return;
+    hipLaunchKernelGGL(k_sort_small<1>, dim3(b.n_structures), dim3(1024), 0, stream, b);
+    hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
+}
+
+// Batch-wide binning of the other structures (the tail).  Independent of launch_sort_lds: the
+// context runs it on a second stream, next to the LDS binning and the first occlusion launch.
+void launch_sort_tail(const BatchView &b, hipStream_t stream)
+{
     hipLaunchKernelGGL(k_zero_cells, dim3(2048), dim3(256), 0, stream, b);
     if (b.n_atoms)
         hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);

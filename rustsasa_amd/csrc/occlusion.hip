@@ -78,11 +78,14 @@ void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream
 }  // namespace
 
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
-                      hipStream_t stream)
+                      OcclusionPart part, hipStream_t stream)
 {
     if (!b.n_atoms) return;
     OccArgs a{b, lat, 0, 1, tune.debug_stop};
     const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
+    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && n_chunks <= 2 &&
+                      lat.n_points - lat.n_fused <= kFastMaxRem;
+    if (!fast && part == kOccHead) return;  // only the fast kernel takes a partial range
     if (tune.kernel_version == 0) {
         // reference kernel: all candidates against all points, one atom per wave
         a.n_blocks = cdiv(b.n_atoms, 4);
@@ -91,8 +94,6 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         else launch_v0<16>(a, stream);
         return;
     }
-    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && n_chunks <= 2 &&
-                      lat.n_points - lat.n_fused <= kFastMaxRem;
     if (tune.atoms_per_wave > 0) {
         a.atoms_per_wave = tune.atoms_per_wave;
     } else {
@@ -108,12 +109,14 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     OccArgs3 a3 = make_args3(a);
     if (fast) {
         // straight-line kernel for every atom it can take; the rest go through the general kernel
-        a3.work_list_out = b.cell_of;  // dead since k_scatter
+        a3.work_list_out = b.deferred_list;
         a3.work_count_out = &b.status->deferred;
         const bool rem = lat.n_points != lat.n_fused;
         const bool half1 = lat.n_fused <= 96u;  // the second chunk's fused points fit half a wave
+        a3.part = part;
         launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
-        a3.work_list = b.cell_of;
+        if (part == kOccHead) return;  // the general kernel follows the last fast launch
+        a3.work_list = b.deferred_list;
         a3.work_count = &b.status->deferred;
         a3.atoms_per_wave = 1;
         const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), 2048u);

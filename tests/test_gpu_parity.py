@@ -312,7 +312,8 @@ def test_full_proteome_properties(ctx):
                                  {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "1"},
                                  {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "7"},
                                  {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "1"},
-                                 {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "3"}])
+                                 {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "3"},
+                                 {"RSASA_OVERLAP_TAIL": "1"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """Every occlusion kernel variant / wave schedule gives bit-identical results."""
     import rustsasa_amd
@@ -437,8 +438,10 @@ def test_fast_kernel_defers_dense_atoms_inside_a_mixed_batch(ctx):
     assert k_blob.max() > 160
 
 
-def test_grid_build_paths_mixed(ctx):
-    """Cell binning has three routes: one workgroup per structure with 16-bit LDS counters (two
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_grid_build_paths_mixed(overlap, monkeypatch):
+    """(overlap = 1: the tail's binning runs on the context's side stream next to the occlusion
+    launch over the LDS-binned structures.)  Cell binning has three routes: one workgroup per structure with 16-bit LDS counters (two
     size tiers), and the batch-wide histogram / scan / scatter for structures with more than
     73 728 cells or 65 535 atoms.  One batch with all of them, interleaved, plus empty structures."""
     rng = np.random.default_rng(17)
@@ -457,7 +460,11 @@ def test_grid_build_paths_mixed(ctx):
     r = rng.uniform(1.2, 2.0, len(xyz)).astype(np.float32)
     ids = np.arange(len(xyz), dtype=np.uint64)
     b = bw.Batch(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), r, ids, so, so)
-    atom, _, k = _device_run(ctx, b, want_res=False)
+    import rustsasa_amd
+    monkeypatch.setenv("RSASA_OVERLAP_TAIL", overlap)
+    with rustsasa_amd.Context(0) as c:
+        for _ in range(3):  # repeated batches reuse the side stream and its events
+            atom, _, k = _device_run(c, b, want_res=False)
     want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, so, PROBE, 100, 8, threads=8)
     assert np.array_equal(atom, want)
 
