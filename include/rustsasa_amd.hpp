@@ -143,12 +143,15 @@ struct OptionValues {
     bool include_hetatms = false;     // options.rs:506
     bool read_radii_from_occupancy = false;  // options.rs:507
     rsasa_context_t *context = nullptr;      // GPU context; nullptr = the library's default (device 0)
+    // process_files only: one GPU worker thread per context (one context per GPU), fed from a queue
+    // of parsed chunks.  Empty = {context}.
+    std::vector<rsasa_context_t *> contexts;
 };
 
 // Wall-clock split of SASAOptions::process_files.
 struct FilesTimings {
-    double parse_seconds = 0;    // reading + parsing + atom selection on the host threads
-    double compute_seconds = 0;  // packing, H2D, GPU hot path, D2H, result mapping
+    double parse_seconds = 0;    // reading + parsing + atom selection on the host threads (producer, summed)
+    double compute_seconds = 0;  // packing, H2D, GPU hot path, D2H, result mapping (GPU workers, summed; overlaps parsing)
     double total_seconds = 0;
     std::size_t n_files = 0, n_atoms = 0;
 };
@@ -182,15 +185,20 @@ public:
     }
     SASAOptions &with_allow_vdw_fallback(bool v) { o_.allow_vdw_fallback = v; return *this; }
     SASAOptions &with_context(rsasa_context_t *ctx) { o_.context = ctx; return *this; }
+    // directory mode over several GPUs: one context per device (rsasa_context_create(device, ...))
+    SASAOptions &with_contexts(std::vector<rsasa_context_t *> ctxs) { o_.contexts = std::move(ctxs); return *this; }
     const OptionValues &values() const { return o_; }
 
     // options.rs:606-618
     Result<typename Level::Output> process(const Structure &pdb) const;
 
     // Directory mode at library level (reference src/main.rs:342-480, `files.par_iter()` :375):
-    // parse + select on `host_threads` threads (0 = min(16, all)), then ONE GPU batch per
-    // `files_per_batch` structures (0 = 4096).  A file that fails (unreadable, missing radius,
-    // ...) gets its own error; the others are unaffected (main.rs:446-454).
+    // chunks of `files_per_batch` files (0 = 256) are parsed + selected on `host_threads` threads
+    // (0 = min(16, all)) and queued; one worker thread per GPU context (with_contexts) takes a
+    // chunk, runs it as ONE GPU batch and builds the results while the next chunk is being
+    // parsed.  Structures are independent, so several GPUs need no exchange.  A file that fails
+    // (unreadable, missing radius, ...) gets its own error; the others are unaffected
+    // (main.rs:446-454).
     std::vector<Result<typename Level::Output>> process_files(const std::vector<std::string> &paths,
                                                               unsigned host_threads = 0,
                                                               std::size_t files_per_batch = 0,

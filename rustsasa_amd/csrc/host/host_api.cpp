@@ -8,6 +8,9 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -962,39 +965,97 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // parsing is allocation heavy and stops scaling early (measured: 8-16 threads on a
     // 256-thread host), so the default is capped
     if (host_threads == 0) host_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    if (files_per_batch == 0) files_per_batch = 4096;
+    if (files_per_batch == 0) files_per_batch = 256;
+    // one worker per given context; with a single context two workers share it (calls on a context
+    // are serialised, but packing, result building and freeing of two chunks then overlap)
+    std::vector<rsasa_context_t *> contexts = o.contexts;
+    if (contexts.empty()) contexts.push_back(o.context);
+    if (contexts.size() == 1) contexts.push_back(contexts[0]);
+
+    struct Chunk {
+        size_t base = 0, n = 0;
+        std::vector<Structure> pdbs;
+        std::vector<Prepared> prep;
+    };
+    // bounded queue: the producer (this thread + its parse pool) stays at most one chunk per
+    // worker ahead, so memory holds a few chunks of parsed structures, not the whole directory
+    std::mutex mu;
+    std::condition_variable cv_push, cv_pop;
+    std::deque<std::unique_ptr<Chunk>> queue;
+    bool closed = false;
+    const size_t capacity = contexts.size() + 1;
     FilesTimings t{};
+    std::mutex mu_t;
+
+    auto worker = [&](rsasa_context_t *ctx) {
+        OptionValues mine = o;
+        mine.context = ctx;
+        for (;;) {
+            std::unique_ptr<Chunk> c;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_pop.wait(lk, [&] { return closed || !queue.empty(); });
+                if (queue.empty()) return;
+                c = std::move(queue.front());
+                queue.pop_front();
+            }
+            cv_push.notify_one();
+            const auto t1 = Clock::now();
+            std::vector<const Structure *> ptrs(c->n);
+            for (size_t i = 0; i < c->n; i++) ptrs[i] = &c->pdbs[i];
+            std::vector<Result<typename Level::Output>> out;
+            run_batch<Level>(mine, ptrs, c->prep, out, std::max(1u, host_threads / 2));
+            for (size_t i = 0; i < c->n; i++) all[c->base + i] = std::move(out[i]);
+            // the parsed structures are freed here, off the producer's path (many small blocks)
+            parallel_for(c->n, std::max(1u, host_threads / 2), [&](size_t i) {
+                Structure s = std::move(c->pdbs[i]);
+                Prepared pr = std::move(c->prep[i]);
+            });
+            c.reset();
+            const double dt = std::chrono::duration<double>(Clock::now() - t1).count();
+            std::lock_guard<std::mutex> lk(mu_t);
+            t.compute_seconds += dt;
+        }
+    };
     const auto t_begin = Clock::now();
+    std::vector<std::thread> workers;
+    for (rsasa_context_t *ctx : contexts) workers.emplace_back(worker, ctx);
+
     for (size_t base = 0; base < paths.size(); base += files_per_batch) {
-        const size_t n = std::min(files_per_batch, paths.size() - base);
-        std::vector<Structure> pdbs(n);
-        std::vector<Prepared> prep(n);
-        std::vector<std::string> open_error(n);
+        auto c = std::make_unique<Chunk>();
+        c->base = base;
+        c->n = std::min(files_per_batch, paths.size() - base);
+        c->pdbs.resize(c->n);
+        c->prep.resize(c->n);
         const auto t0 = Clock::now();
-        parallel_for(n, host_threads, [&](size_t i) {
+        parallel_for(c->n, host_threads, [&](size_t i) {
             try {
-                pdbs[i] = Structure::open(paths[base + i]);
-                prep[i] = prepare<Level>(pdbs[i], o);
-            } catch (const std::exception &e) {
-                open_error[i] = e.what();
+                c->pdbs[i] = Structure::open(paths[base + i]);
+                c->prep[i] = prepare<Level>(c->pdbs[i], o);
+            } catch (const std::exception &e) {  // unreadable file: report, keep going (main.rs:446-454)
+                c->prep[i] = Prepared{};
+                c->prep[i].err = {SASACalcError::Engine, std::string("cannot read structure: ") + e.what()};
             }
         });
-        const auto t1 = Clock::now();
-        std::vector<const Structure *> ptrs(n);
-        for (size_t i = 0; i < n; i++) {
-            ptrs[i] = &pdbs[i];
-            if (!open_error[i].empty()) {  // unreadable file: report, keep going (main.rs:446-454)
-                prep[i].err = {SASACalcError::Engine, "cannot read structure: " + open_error[i]};
-            }
-            t.n_atoms += prep[i].atoms.size();
+        size_t atoms = 0;
+        for (size_t i = 0; i < c->n; i++) atoms += c->prep[i].atoms.size();
+        {
+            std::lock_guard<std::mutex> lk(mu_t);
+            t.parse_seconds += std::chrono::duration<double>(Clock::now() - t0).count();
+            t.n_atoms += atoms;
         }
-        std::vector<Result<typename Level::Output>> out;
-        run_batch<Level>(o, ptrs, prep, out, host_threads);
-        const auto t2 = Clock::now();
-        for (size_t i = 0; i < n; i++) all[base + i] = std::move(out[i]);
-        t.parse_seconds += std::chrono::duration<double>(t1 - t0).count();
-        t.compute_seconds += std::chrono::duration<double>(t2 - t1).count();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_push.wait(lk, [&] { return queue.size() < capacity; });
+        queue.push_back(std::move(c));
+        lk.unlock();
+        cv_pop.notify_one();
     }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        closed = true;
+    }
+    cv_pop.notify_all();
+    for (auto &th : workers) th.join();
     t.total_seconds = std::chrono::duration<double>(Clock::now() - t_begin).count();
     t.n_files = paths.size();
     if (timings) *timings = t;

@@ -64,13 +64,29 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     unsigned threads = 0;
     size_t batch = 0;
     bool full = false;
+    int workers = 0, devices = 1;  // --workers K: K GPU worker contexts, on devices k % --devices
     for (int i = 4; i < argc; i++) {
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (size_t)std::atol(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--workers") && i + 1 < argc) workers = std::atoi(argv[i + 1]);
+        if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, std::atoi(argv[i + 1]));
         if (!std::strcmp(argv[i], "--full")) full = true;
     }
+    std::vector<rsasa_context_t *> ctxs;
+    for (int k = 0; k < workers; k++) {
+        rsasa_context_t *c = nullptr;
+        const int rc = rsasa_context_create(k % devices, &c);
+        if (rc != RSASA_OK) {
+            std::fprintf(stderr, "rsasa_context_create(%d): %s\n", k % devices, rsasa_status_string(rc));
+            return 70;
+        }
+        ctxs.push_back(c);
+    }
     FilesTimings t;
-    auto res = make<L>(argc - 1, argv + 1).process_files(paths, threads, batch, &t);
+    auto opts = make<L>(argc - 1, argv + 1);
+    if (!ctxs.empty()) opts.with_contexts(ctxs);
+    auto res = opts.process_files(paths, threads, batch, &t);
+    for (rsasa_context_t *c : ctxs) rsasa_context_destroy(c);
     size_t n_ok = 0;
     for (const auto &r : res) n_ok += r.ok();
     std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"results\":[",

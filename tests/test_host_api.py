@@ -242,11 +242,13 @@ def test_process_files_reports_errors_per_file(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [0, 5])
-def test_process_files_matches_oracle(tmp_path, batch):
+@pytest.mark.parametrize("batch,workers", [(0, 0), (5, 0), (3, 3)])
+def test_process_files_matches_oracle(tmp_path, batch, workers):
+    """Chunks of `batch` files go through a queue to `workers` GPU worker threads, each with its own
+    context (here all on device 0; one per GPU in production): results keep the input order."""
     paths, lst = _make_file_set(tmp_path, 12)
-    p = subprocess.run([CLI, "files", "residue", lst, "--threads", "4", "--batch", str(batch), "--full"],
-                       capture_output=True, text=True)
+    p = subprocess.run([CLI, "files", "residue", lst, "--threads", "4", "--batch", str(batch), "--full",
+                        "--workers", str(workers), "--devices", "1"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[:500]
     got = json.loads(p.stdout)
     assert got["n_ok"] == len(paths) - 2

@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--dir", default=None)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--workers", type=int, default=0, help="GPU worker contexts (0 = the default context)")
+    ap.add_argument("--devices", type=int, default=1)
     args = ap.parse_args()
     d = args.dir or tempfile.mkdtemp(prefix="rsasa_files_")
     rng = np.random.default_rng(bw.PROTEOME_SEED)
@@ -98,7 +100,8 @@ def main():
     gen_s = time.time() - t0
     best = None
     for _ in range(args.repeat):
-        cmd = [CLI, "files", "residue", lst, "--threads", str(args.threads), "--batch", str(args.batch)]
+        cmd = [CLI, "files", "residue", lst, "--threads", str(args.threads), "--batch", str(args.batch),
+               "--workers", str(args.workers), "--devices", str(args.devices)]
         p = subprocess.run(cmd, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr[-500:]
         r = json.loads(p.stdout)
