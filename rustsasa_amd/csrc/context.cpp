@@ -85,6 +85,9 @@ struct rsasa_context {
         sorted_orig, sorted_id, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
+    DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res;  // second input slot of the pipelined host-buffer path
+    hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
     DeviceBuffer tr_xyz, tr_r, tr_id, tr_res;  // trajectory staging (frame-major xyz, per-topology columns)
     // pinned host
     Segment *h_segments = nullptr;
@@ -424,6 +427,8 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&ctx->h_status, sizeof(BatchStatus), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -448,6 +453,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
+                            &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->tr_xyz, &ctx->tr_r,
                             &ctx->tr_id, &ctx->tr_res})
         release(*b);
@@ -457,6 +463,9 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (int i = 0; i < 4; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 2; i++)
+        if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -587,54 +596,114 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    {
-        RS_HIP(ctx, hipSetDevice(ctx->device));
-        if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
-        const size_t n1 = std::max<size_t>(N, 1);
-        if ((rc = reserve(ctx, ctx->in_x, n1 * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->in_y, n1 * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->in_z, n1 * 4))) return rc;
-        if ((rc = reserve(ctx, ctx->in_r, n1 * 4))) return rc;
-        if (id && (rc = reserve(ctx, ctx->in_id, n1 * 8))) return rc;
-        if ((rc = reserve(ctx, ctx->atom_sasa, n1 * 4))) return rc;
-        if (want_res) {
-            if ((rc = reserve(ctx, ctx->in_res, (n_residues + 1) * 4))) return rc;
-            if ((rc = reserve(ctx, ctx->out_res, n_residues * 4))) return rc;
+    RS_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+
+    // Large batches are cut into sub-batches of whole structures (and whole residues) whose
+    // host-to-device copies run on a second stream into a second set of input buffers while the
+    // previous sub-batch computes: the PCIe transfer hides behind the kernels.
+    const size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
+    std::vector<size_t> cut{0};        // structure indices where sub-batches begin / end
+    if (N >= 2 * kSubAtoms && n_structures > 1) {
+        const size_t n_sub = std::min<size_t>(8, N / kSubAtoms);
+        size_t next = 1;
+        for (size_t sidx = 1; sidx < n_structures && next < n_sub; sidx++) {
+            const size_t a0 = structure_offsets[sidx];
+            if (a0 < next * (N / n_sub)) continue;
+            if (want_res && !std::binary_search(residue_offsets, residue_offsets + n_residues + 1, (uint32_t)a0))
+                continue;  // a residue spans this structure boundary: cut later
+            cut.push_back(sidx);
+            next = a0 / (N / n_sub) + 1;
         }
-        hipStream_t st = ctx->stream;
-        if (N) {
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_x.p, x, N * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_y.p, y, N * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_z.p, z, N * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_r.p, radius, N * 4, hipMemcpyHostToDevice, st));
-            if (id) RS_HIP(ctx, hipMemcpyAsync(ctx->in_id.p, id, N * 8, hipMemcpyHostToDevice, st));
-        }
-        if (want_res)
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_res.p, residue_offsets, (n_residues + 1) * 4,
-                                       hipMemcpyHostToDevice, st));
     }
+    cut.push_back(n_structures);
+    size_t max_atoms = 1, max_res = 1;
+    std::vector<size_t> res_cut(cut.size(), 0);
+    for (size_t c = 0; c + 1 < cut.size(); c++) {
+        max_atoms = std::max<size_t>(max_atoms, structure_offsets[cut[c + 1]] - structure_offsets[cut[c]]);
+        if (want_res) {
+            res_cut[c + 1] = c + 2 == cut.size()
+                                 ? n_residues
+                                 : (size_t)(std::lower_bound(residue_offsets, residue_offsets + n_residues + 1,
+                                                             structure_offsets[cut[c + 1]]) - residue_offsets);
+            max_res = std::max(max_res, res_cut[c + 1] - res_cut[c]);
+        }
+    }
+    const bool piped = cut.size() > 2;
+    DeviceBuffer *bx[2] = {&ctx->in_x, &ctx->in2_x}, *by[2] = {&ctx->in_y, &ctx->in2_y};
+    DeviceBuffer *bz[2] = {&ctx->in_z, &ctx->in2_z}, *br[2] = {&ctx->in_r, &ctx->in2_r};
+    DeviceBuffer *bi[2] = {&ctx->in_id, &ctx->in2_id}, *bo[2] = {&ctx->in_res, &ctx->in2_res};
+    for (int k = 0; k < (piped ? 2 : 1); k++) {
+        if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
+        if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
+        if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
+        if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
+        if (id && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
+        if (want_res && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
+    }
+    if ((rc = reserve(ctx, ctx->atom_sasa, max_atoms * 4))) return rc;
+    if (want_res && (rc = reserve(ctx, ctx->out_res, max_res * 4))) return rc;
 
-    rsasa_device_batch_t bt{};
-    bt.x = (const float *)ctx->in_x.p;
-    bt.y = (const float *)ctx->in_y.p;
-    bt.z = (const float *)ctx->in_z.p;
-    bt.radius = (const float *)ctx->in_r.p;
-    bt.id = id ? (const uint64_t *)ctx->in_id.p : nullptr;
-    bt.structure_offsets_host = structure_offsets;
-    bt.n_structures = n_structures;
-    bt.n_atoms = N;
-    bt.residue_offsets = want_res ? (const uint32_t *)ctx->in_res.p : nullptr;
-    bt.n_residues = want_res ? n_residues : 0;
-    bt.out_atom_sasa = (float *)ctx->atom_sasa.p;
-    bt.out_residue_sasa = want_res ? (float *)ctx->out_res.p : nullptr;
-    bt.out_neighbor_counts = nullptr;
-    if ((rc = rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr))) return rc;
-    if ((rc = rsasa_batch_wait(ctx))) return rc;
+    // host copies of the rebased offsets stay alive until their sub-batch has been waited for
+    std::vector<uint32_t> so[2], ro[2];
+    auto upload = [&](size_t c, hipStream_t st) -> int {
+        const int k = (int)(c & 1);
+        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
+        so[k].resize(s1 - s0 + 1);
+        for (size_t i = s0; i <= s1; i++) so[k][i - s0] = structure_offsets[i] - (uint32_t)a0;
+        if (na) {
+            RS_HIP(ctx, hipMemcpyAsync(bx[k]->p, x + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
+            if (id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
+        }
+        if (want_res) {
+            const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
+            ro[k].resize(r1 - r0 + 1);
+            for (size_t i = r0; i <= r1; i++) ro[k][i - r0] = residue_offsets[i] - (uint32_t)a0;
+            RS_HIP(ctx, hipMemcpyAsync(bo[k]->p, ro[k].data(), (r1 - r0 + 1) * 4, hipMemcpyHostToDevice, st));
+        }
+        return RSASA_OK;
+    };
 
-    if (out_atom_sasa && N)
-        RS_HIP(ctx, hipMemcpy(out_atom_sasa, ctx->atom_sasa.p, N * 4, hipMemcpyDeviceToHost));
-    if (want_res)
-        RS_HIP(ctx, hipMemcpy(out_residue_sasa, ctx->out_res.p, n_residues * 4, hipMemcpyDeviceToHost));
+    hipStream_t st = ctx->stream, cp = piped ? ctx->copy_stream : ctx->stream;
+    if ((rc = upload(0, cp))) return rc;
+    if (piped) RS_HIP(ctx, hipEventRecord(ctx->ev_copy[0], cp));
+    for (size_t c = 0; c + 1 < cut.size(); c++) {
+        const int k = (int)(c & 1);
+        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
+        const size_t r0 = res_cut[c], nr = want_res ? res_cut[c + 1] - r0 : 0;
+        if (piped) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
+        rsasa_device_batch_t bt{};
+        bt.x = (const float *)bx[k]->p;
+        bt.y = (const float *)by[k]->p;
+        bt.z = (const float *)bz[k]->p;
+        bt.radius = (const float *)br[k]->p;
+        bt.id = id ? (const uint64_t *)bi[k]->p : nullptr;
+        bt.structure_offsets_host = so[k].data();
+        bt.n_structures = s1 - s0;
+        bt.n_atoms = na;
+        bt.residue_offsets = nr ? (const uint32_t *)bo[k]->p : nullptr;
+        bt.n_residues = nr;
+        bt.out_atom_sasa = (float *)ctx->atom_sasa.p;
+        bt.out_residue_sasa = nr ? (float *)ctx->out_res.p : nullptr;
+        bt.out_neighbor_counts = nullptr;
+        const bool run = na || nr;
+        if (run && (rc = rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr))) return rc;
+        // The kernels of sub-batch c are queued; now feed the next one.  (A copy from pageable
+        // memory keeps this thread busy, so it has to come after the enqueue to overlap.)  Slot
+        // k ^ 1 was last read by sub-batch c - 1, which has been waited for.
+        if (piped && c + 2 < cut.size()) {
+            if ((rc = upload(c + 1, cp))) return rc;
+            RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k ^ 1], cp));
+        }
+        if (run && (rc = rsasa_batch_wait(ctx))) return rc;
+        if (out_atom_sasa && na)
+            RS_HIP(ctx, hipMemcpy(out_atom_sasa + a0, ctx->atom_sasa.p, na * 4, hipMemcpyDeviceToHost));
+        if (nr)
+            RS_HIP(ctx, hipMemcpy(out_residue_sasa + r0, ctx->out_res.p, nr * 4, hipMemcpyDeviceToHost));
+    }
     return RSASA_OK;
 }
 

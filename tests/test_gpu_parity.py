@@ -483,3 +483,33 @@ def test_many_tiny_structures(ctx):
     atom, _, _ = _device_run(ctx, b, want_res=False)
     want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, so, PROBE, 100, 8, threads=8)
     assert np.array_equal(atom, want)
+
+
+def test_host_batch_pipelined_sub_batches(ctx):
+    """rsasa_calculate_sasa_batch cuts a large host batch into sub-batches of whole structures (and
+    whole residues) and overlaps their uploads with compute.  The result must equal the
+    device-resident single-batch run, also when the residue segments ignore structure boundaries."""
+    b = bw.synthetic_proteome(1300, seed=31)
+    assert b.n_atoms > 3_000_000
+    atom_dev, res_dev, _ = _device_run(ctx, b, want_k=False)
+    atom, res = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                         residue_offsets=b.residue_offsets)
+    assert np.array_equal(atom, atom_dev) and np.array_equal(res, res_dev)
+    # residues only (no per-atom output)
+    _, res2 = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                       residue_offsets=b.residue_offsets, want_atoms=False)
+    assert np.array_equal(res2, res_dev)
+    # segments of 7 atoms across the whole array: most structure boundaries are not segment boundaries
+    seg = np.arange(0, b.n_atoms + 1, 7, dtype=np.uint32)
+    if seg[-1] != b.n_atoms:
+        seg = np.append(seg, np.uint32(b.n_atoms))
+    _, res7 = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                       residue_offsets=seg, want_atoms=False)
+    want7 = po.residue_sums(atom_dev, seg)
+    assert np.array_equal(res7, want7)
+    # a few structures against the oracle
+    rng = np.random.default_rng(3)
+    for s in rng.choice(b.n_structures, 6, replace=False):
+        lo, hi = int(b.structure_offsets[s]), int(b.structure_offsets[s + 1])
+        want = po.calculate_sasa_internal(*b.structure(int(s)), PROBE, 100, 8)
+        assert np.array_equal(atom[lo:hi], want)
