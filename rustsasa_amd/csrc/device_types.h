@@ -126,6 +126,11 @@ void launch_expand_frames(const float *xyz, const float *radius, const uint64_t 
 
 constexpr uint32_t kSegmentAtoms = 4096;  // atoms per bounds workgroup
 constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
-constexpr uint32_t kLdsCells = 73728;     // cells k_sort_small bins in LDS (16-bit counters, 144 KiB)
+constexpr uint32_t kLdsCells = 73728;     // cells k_sort_small bins in LDS per pass (16-bit counters, 144 KiB)
+#ifndef RSASA_MAX_LDS_WINDOWS
+#define RSASA_MAX_LDS_WINDOWS 3
+#endif
+constexpr uint32_t kMaxLdsWindows = RSASA_MAX_LDS_WINDOWS;  // larger grids go to the batch-wide kernels: one
+                                                            // workgroup walking many windows is the slowest in the launch
 
 }  // namespace rsasa

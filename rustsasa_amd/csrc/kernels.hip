@@ -106,8 +106,10 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
     g.n_cells = (uint32_t)nc;
     g.atom_begin = a.n_atoms ? a.first_atom : 0u;
     g.n_atoms = a.n_atoms;
-    // 16-bit LDS counters and prefixes: two LDS tiers (k_sort_small), else the batch-wide kernels
-    g.in_lds = a.n_atoms >= 65536u ? 0u : (g.n_cells <= kLdsCells / 2 ? 1u : (g.n_cells <= kLdsCells ? 2u : 0u));
+    // 16-bit LDS counters and prefixes: fewer than 65536 atoms and at most kMaxLdsWindows windows of
+    // cells -> one workgroup bins the structure in LDS (k_sort_small: small grids two workgroups
+    // per CU, larger ones window by window); else the batch-wide kernels
+    g.in_lds = (a.n_atoms >= 65536u || g.n_cells > kMaxLdsWindows * kLdsCells) ? 0u : (g.n_cells <= kLdsCells / 2 ? 1u : 2u);
     return g;
 }
 
@@ -222,101 +224,124 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
 // histogram with LDS atomics, in-place exclusive scan, then the cell starts and the sorted atoms
 // go to global memory.  Replaces k_zero_cells / k_cell_hist / k_scan_* / k_scatter for that
 // structure: the batch-wide cell array is written once and never read back.
-template <uint32_t TIER>  // 1: up to kLdsCells / 2 cells (two workgroups per CU), 2: up to kLdsCells
+template <uint32_t TIER>  // 1: up to kLdsCells / 2 cells (two workgroups per CU), 2: any number of cells
 __global__ __launch_bounds__(1024) void k_sort_small(BatchView b)
 {
     if (batch_aborted(b.status)) return;
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kLdsCells / (TIER == 1 ? 4 : 2)];
+    constexpr uint32_t kWindow = kLdsCells / (TIER == 1 ? 2 : 1);  // cells binned per pass
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindow / 2];
     __shared__ uint32_t smem32[16];
     const uint32_t s = blockIdx.x;
     const StructGrid g = b.grids[s];
     if (g.in_lds != TIER) return;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_cells = g.n_cells, n_words = (n_cells + 1u) >> 1;
     const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
-    {
-        uint4 *z4 = reinterpret_cast<uint4 *>(s_cnt);
-        for (uint32_t i = tid; i < (n_words + 3u) / 4u; i += 1024u) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    __syncthreads();
-    // spatial_grid.rs:53-62; the atomic's return value is the atom's slot inside its cell.
-    // Four atoms per trip, loads first: one workgroup per CU has little else to hide latency with.
     const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z, *__restrict__ pr = b.radius;
-    uint32_t *__restrict__ cell_of = b.cell_of, *__restrict__ rank_of = b.rank_of;
-    for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
-        float x[4], y[4], z[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
-            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
-        }
-        uint32_t c[4], old[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t cx, cy, cz;
-            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
-            c[k] = cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
-            if (i0 + 1024u * k < a1) old[k] = atomicAdd(&s_cnt[c[k] >> 1], 1u << ((c[k] & 1u) * 16u));
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = i0 + 1024u * k;
-            if (i < a1) {
-                cell_of[i] = c[k];
-                rank_of[i] = (old[k] >> ((c[k] & 1u) * 16u)) & 0xFFFFu;
-            }
-        }
-    }
-    __syncthreads();
-    // exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive words
-    // (odd stride: no bank conflicts), sums them, the partial sums are scanned across the
-    // workgroup, and the words are rewritten as (prefix of the even cell | prefix of the odd one << 16)
-    const uint32_t per = ((n_words + 1023u) / 1024u) | 1u;
-    const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
-    uint32_t sum = 0;
-    for (uint32_t j = w0; j < w1; j++) {
-        const uint32_t v = s_cnt[j];
-        sum += (v & 0xFFFFu) + (v >> 16);
-    }
-    uint32_t total;
-    uint32_t running = block_incl_scan<16>(sum, smem32, total) - sum;
-    for (uint32_t j = w0; j < w1; j++) {
-        const uint32_t v = s_cnt[j];
-        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-        s_cnt[j] = running | ((running + lo) << 16);  // < 65536: the structure has < 65536 atoms
-        running += lo + hi;
-    }
-    __syncthreads();
-    // cell starts, plus the end marker that the last cell's run length is read from
-    for (uint32_t c = tid; c <= n_cells; c += 1024u) {
-        const uint32_t pre = c < n_cells ? (s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : g.n_atoms;
-        b.cells[g.cell_base + c] = g.sorted_base + pre;
-    }
-    // scatter (spatial_grid.rs:70-93), four atoms per trip
     const uint64_t *__restrict__ pid = b.id;
-    for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
-        uint32_t c[4], rk[4];
-        float4 v[4];
-        uint64_t id[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
-            c[k] = cell_of[i]; rk[k] = rank_of[i];
-            v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
-            id[k] = pid ? pid[i] : 0ull;
+    uint32_t *__restrict__ cell_of = b.cell_of, *__restrict__ rank_of = b.rank_of;
+    // A grid larger than the LDS window is binned window by window (cells [c0, c0 + kWindow)):
+    // atoms outside the window are skipped and come back in their own pass.  `placed` = atoms of
+    // the windows before, i.e. the first sorted position of this window's atoms.
+    uint32_t placed = 0;
+    for (uint32_t c0 = 0; c0 < g.n_cells; c0 += kWindow) {
+        const uint32_t n_cells = min(kWindow, g.n_cells - c0), n_words = (n_cells + 1u) >> 1;
+        const bool first = c0 == 0u;
+        {
+            uint4 *z4 = reinterpret_cast<uint4 *>(s_cnt);
+            for (uint32_t i = tid; i < (n_words + 3u) / 4u; i += 1024u) z4[i] = make_uint4(0u, 0u, 0u, 0u);
         }
+        __syncthreads();
+        // spatial_grid.rs:53-62; the atomic's return value is the atom's slot inside its cell.
+        // Four atoms per trip, loads first: one workgroup per CU has little else to hide latency with.
+        for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
+            uint32_t c[4], old[4];
+            if (first) {
+                float x[4], y[4], z[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t i = i0 + 1024u * k;
-            if (i < a1) {
-                const uint32_t pos = g.sorted_base + ((s_cnt[c[k] >> 1] >> ((c[k] & 1u) * 16u)) & 0xFFFFu) + rk[k];
-                b.sorted_xyzr[pos] = v[k];
-                b.sorted_orig[pos] = i;
-                b.sid_sorted[pos] = s;
-                if (pid) b.sorted_id[pos] = id[k];
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+                    x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t cx, cy, cz;
+                    cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+                    c[k] = cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) c[k] = cell_of[min(i0 + 1024u * k, a1 - 1u)];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t lc = c[k] - c0;
+                old[k] = 0;
+                if (i0 + 1024u * k < a1 && lc < n_cells) old[k] = atomicAdd(&s_cnt[lc >> 1], 1u << ((lc & 1u) * 16u));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + 1024u * k, lc = c[k] - c0;
+                if (i < a1) {
+                    if (first) cell_of[i] = c[k];
+                    if (lc < n_cells) rank_of[i] = (old[k] >> ((lc & 1u) * 16u)) & 0xFFFFu;
+                }
             }
         }
+        __syncthreads();
+        // exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive
+        // words (odd stride: no bank conflicts), sums them, the partial sums are scanned across the
+        // workgroup, and the words are rewritten as (prefix of the even cell | prefix of the odd
+        // one << 16), counted from the structure's first atom: < 65536, it has < 65536 atoms
+        const uint32_t per = ((n_words + 1023u) / 1024u) | 1u;
+        const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
+        uint32_t sum = 0;
+        for (uint32_t j = w0; j < w1; j++) {
+            const uint32_t v = s_cnt[j];
+            sum += (v & 0xFFFFu) + (v >> 16);
+        }
+        uint32_t total;
+        uint32_t running = placed + block_incl_scan<16>(sum, smem32, total) - sum;
+        for (uint32_t j = w0; j < w1; j++) {
+            const uint32_t v = s_cnt[j];
+            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+            s_cnt[j] = running | ((running + lo) << 16);
+            running += lo + hi;
+        }
+        __syncthreads();
+        // cell starts; after the last window the end marker that the last cell's run length is read from
+        const uint32_t n_write = n_cells + (c0 + n_cells == g.n_cells ? 1u : 0u);
+        for (uint32_t c = tid; c < n_write; c += 1024u) {
+            const uint32_t pre = c < n_cells ? (s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : g.n_atoms;
+            b.cells[g.cell_base + c0 + c] = g.sorted_base + pre;
+        }
+        // scatter (spatial_grid.rs:70-93), four atoms per trip
+        for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
+            uint32_t c[4], rk[4];
+            float4 v[4];
+            uint64_t id[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+                c[k] = cell_of[i] - c0; rk[k] = rank_of[i];
+                v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
+                id[k] = pid ? pid[i] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = i0 + 1024u * k;
+                if (i < a1 && c[k] < n_cells) {
+                    const uint32_t pos = g.sorted_base + ((s_cnt[c[k] >> 1] >> ((c[k] & 1u) * 16u)) & 0xFFFFu) + rk[k];
+                    b.sorted_xyzr[pos] = v[k];
+                    b.sorted_orig[pos] = i;
+                    b.sid_sorted[pos] = s;
+                    if (pid) b.sorted_id[pos] = id[k];
+                }
+            }
+        }
+        placed += total;
+        __syncthreads();  // the counters are zeroed again for the next window
     }
+    if (g.n_cells == 0u && tid == 0u) b.cells[g.cell_base] = g.sorted_base;
 }
 
 // ---- batch-wide path for the structures of the tail (cells do not fit the LDS) ----

@@ -446,11 +446,12 @@ def test_grid_build_paths_mixed(overlap, monkeypatch):
     73 728 cells or 65 535 atoms.  One batch with all of them, interleaved, plus empty structures."""
     rng = np.random.default_rng(17)
     parts = []
-    # tier 1 (compact), tier 2 (elongated: ~50 k cells), tail by cells (very elongated), tail by atoms
+    # tier 1 (compact), tier 2 (elongated: ~50 k cells), windowed (very elongated), tail by cells, tail by atoms
     parts.append(rng.uniform(0, 30, size=(900, 3)))
     parts.append(rng.uniform(0, 1, size=(700, 3)) * np.array([900.0, 40.0, 40.0]))
     parts.append(np.zeros((0, 3)))
-    parts.append(rng.uniform(0, 1, size=(800, 3)) * np.array([2500.0, 45.0, 45.0]))
+    parts.append(rng.uniform(0, 1, size=(800, 3)) * np.array([2500.0, 45.0, 45.0]))     # 3 LDS windows
+    parts.append(rng.uniform(0, 1, size=(400, 3)) * np.array([9000.0, 60.0, 60.0]))     # > 16 windows: batch-wide
     parts.append(rng.uniform(0, 25, size=(500, 3)))
     parts.append(rng.uniform(0, 95, size=(70000, 3)))
     parts.append(np.zeros((0, 3)))
