@@ -2,33 +2,40 @@
 //
 // One wavefront per atom, atoms taken in cell-sorted order (a workgroup's four
 // waves work on spatial neighbours, and the XCD-aware remap gives every XCD a
-// contiguous range of structures so its L2 holds only those).
+// contiguous range of structures so its L2 holds only those).  Three kernels make the same
+// decisions:
+//   k_occlusion_fast (occlusion_fast.inc)  the straight-line kernel for the common case
+//       (n_points <= 128, <= 4 remainder points); atoms it cannot take (more than 256 atoms in
+//       the culled runs, more than 144 candidates) go to the batch's deferred list;
+//   k_occlusion_v3 (occlusion_v3.inc)      the general kernel: any n_points (groups of two
+//       64-point chunks), any list length (several flushes), any remainder count; runs over the
+//       deferred list after the fast kernel, or over every atom when the fast one does not apply;
+//   k_occlusion_v0 (occlusion_v0.inc)      all candidates x all points, no culling: an
+//       independent implementation for A/B checks (RSASA_OCCLUSION_KERNEL=0).
 //
-//   PROLOGUE (per wave, all its atoms at once, 64 (atom, run) pairs per pass): the 25 x-runs
-//      of cells of the 5x5x5 block around each atom's cell (search_extent = 2, reference
+// Stages (details differ between fast and v3, see the files):
+//   PROLOGUE (per wave, a group of its atoms at once, 64 (atom, run) pairs per pass): the 25
+//      x-runs of cells of the 5x5x5 block around each atom's cell (search_extent = 2, reference
 //      spatial_grid.rs:47: max_search / cell_size is exactly 2 in f32), culled and trimmed with
 //      a conservative lower bound on the distance.
 //   Then per atom:
 //   1. the run lengths are prefix-summed (DPP); a 256-bit mask of run starts and a per-run
 //      `start - prefix` table map every flat position of the concatenated runs to its atom;
 //   2. SWEEP: 64 flat positions per iteration: the reference's candidate rule
-//      d^2 <= (r_i + max_r + 2p)^2 (spatial_grid.rs:307-308,335); accepted atoms' indices are
-//      appended to the wave's LDS list;
-//   3. PREP (lane = candidate): id rule (:314), v and limit_j (lib.rs:128-136); the list is
-//      rewritten as (vx, vy, vz, limit) records, NEAR candidates (strong occluders) first;
-//   4. remainder points (scalar rule, lib.rs:163-218) in their own pass, lanes tiled (point x
-//      candidate);
-//   5. PHASE A (lane = sphere point): every near candidate is broadcast from LDS and tested
-//      against all fused-rule points (lib.rs:143-147): ~85 % of the points are occluded after
-//      ~10 candidates;
+//      d^2 <= (r_i + max_r + 2p)^2 (spatial_grid.rs:307-308,335); accepted atoms go to the
+//      wave's LDS list (fast: records after the id rule; v3: indices, id rule in the prep pass);
+//   3. PREP (lane = candidate): v and limit_j (lib.rs:128-136); the list becomes
+//      (vx, vy, vz, limit) records, NEAR candidates (strong occluders) first;
+//   4. remainder points (scalar rule, lib.rs:163-218): fast: uniform values tested inside the
+//      prep pass; v3: their own pass, lanes tiled (point x candidate);
+//   5. PHASE A (lane = sphere point): near candidates are broadcast from LDS and tested against
+//      all fused-rule points (lib.rs:143-147): ~90 % of the points are occluded after ~11
+//      candidates;
 //   6. PHASE B: the surviving points are compacted and tested against the far candidates with
-//      lanes tiled as (survivor x candidate), e.g. 16 survivors x 4 candidates per instruction.
-//   For n_points > 128 steps 5-6 repeat per group of two 64-point chunks inside the same sweep.
+//      lanes tiled as (survivor x candidate), e.g. 8 survivors x 8 candidates per instruction.
 //
 // The result is an OR over the candidate set, so the order of tests is free; every individual
-// test uses the reference's exact f32 expressions.  k_occlusion_v0 (all candidates x all
-// points, no culling) is kept as an independent on-GPU implementation for A/B checks
-// (RSASA_OCCLUSION_KERNEL=0).
+// test uses the reference's exact f32 expressions.
 #include "device_utils.h"
 
 namespace rsasa {
