@@ -73,6 +73,7 @@ struct rsasa_context {
     int simd_width = 8;
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool small_path = true;                       // RSASA_SMALL_PATH=0: small host batches take the general path too
     bool overlap_tail = false;                    // RSASA_OVERLAP_TAIL=1: bin the tail on the side stream, next to the first
                                                   // occlusion launch (measured: step -2.5 %, occlusion kernels +5 % from contention)
     hipStream_t side_stream = nullptr;            // runs the tail's binning next to the launch stream
@@ -88,6 +89,9 @@ struct rsasa_context {
     DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res;  // second input slot of the pipelined host-buffer path
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    DeviceBuffer small_in, small_out;          // small host batches: one upload / one download buffer
+    void *h_small = nullptr;                   // pinned staging of the same layout
+    size_t h_small_cap = 0;
     DeviceBuffer tr_xyz, tr_r, tr_id, tr_res;  // trajectory staging (frame-major xyz, per-topology columns)
     // pinned host
     Segment *h_segments = nullptr;
@@ -440,6 +444,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
     if (const char *v = std::getenv("RSASA_DEBUG_STOP")) ctx->tuning.debug_stop = (uint32_t)std::atoi(v);
     if (const char *v = std::getenv("RSASA_OVERLAP_TAIL")) ctx->overlap_tail = std::atoi(v) != 0;
+    if (const char *v = std::getenv("RSASA_SMALL_PATH")) ctx->small_path = std::atoi(v) != 0;
     *out_ctx = ctx;
     return RSASA_OK;
 }
@@ -454,7 +459,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
-                            &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->tr_xyz, &ctx->tr_r,
+                            &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
                             &ctx->tr_id, &ctx->tr_res})
         release(*b);
     for (auto &kv : ctx->lattices)
@@ -466,6 +471,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     for (int i = 0; i < 2; i++)
         if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -567,6 +573,165 @@ int rsasa_batch_wait(rsasa_context_t *ctx)
     return wait_pending(ctx);
 }
 
+namespace {
+
+// Host-side restatement of make_grid (kernels.hip) for the small-batch path: the same IEEE f32
+// operations (this file is compiled with -ffp-contract=off like the device code).
+bool small_grid(const float mn_in[3], const float mx_in[3], float max_r, float probe, uint32_t n_atoms,
+                StructGrid *out)
+{
+    const float cell = probe + max_r;  // lib.rs:76
+    const float inv = 1.0f / cell;     // spatial_grid.rs:36
+    if (!(cell > 0.0f) || !(inv < INFINITY)) return false;
+    StructGrid g{};
+    unsigned long long nc = 1;
+    uint32_t d[3];
+    const float mn[3] = {mn_in[0] - cell, mn_in[1] - cell, mn_in[2] - cell};
+    const float mx[3] = {mx_in[0] + cell, mx_in[1] + cell, mx_in[2] + cell};
+    for (int k = 0; k < 3; k++) {  // spatial_grid.rs:39-43
+        const float e = ceilf((mx[k] - mn[k]) * inv);
+        if (!(e >= 0.0f) || e >= 2147483648.0f) return false;
+        d[k] = (uint32_t)e + 1u;
+        nc *= d[k];
+        if (nc > (unsigned long long)kMaxLdsWindows * kLdsCells) return false;
+    }
+    g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
+    g.inv_cell = inv;
+    g.dim_x = d[0]; g.dim_y = d[1]; g.dim_z = d[2];
+    g.max_r = max_r;
+    g.cell_size = cell;
+    g.n_cells = (uint32_t)nc;
+    g.n_atoms = n_atoms;
+    g.in_lds = 2u;  // k_sort_small<2> takes every structure of a small batch
+    *out = g;
+    return true;
+}
+
+constexpr size_t kSmallAtoms = 32768, kSmallStructures = 256;
+constexpr int kNotSmall = 1;  // (positive: not an error) the batch goes through the general path
+
+// Batches of a few structures handed over in host memory - the literal drop-in use, one
+// calculate_sasa_internal call per structure - are latency bound: ~17 kernel launches and half a
+// dozen small copies.  Here the host computes the bounding boxes and grids itself (N is small),
+// so the device needs ONE upload (inputs + grids + status, through pinned staging), four
+// launches (LDS binning, the two occlusion kernels, residue sums) and one download.
+int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, const float *z,
+                         const float *radius, const uint64_t *id, const uint32_t *so, size_t S,
+                         float probe, size_t n_points, float *out_atom, const uint32_t *ro, size_t R,
+                         float *out_res)
+{
+    // anything unusual is left to the general path, which validates and reports it
+    if (S == 0 || S > kSmallStructures || so[0] != 0 || n_points == 0 || n_points > (1u << 24) ||
+        !(probe >= 0.0f) || !std::isfinite(probe) || ctx->timing || ctx->tuning.debug_stop)
+        return kNotSmall;
+    const size_t N = so[S];
+    if (N == 0 || N > kSmallAtoms) return kNotSmall;
+    std::vector<StructGrid> grids(S);
+    unsigned long long total_cells = 0;
+    for (size_t s = 0; s < S; s++) {
+        if (so[s] > so[s + 1]) return kNotSmall;  // (the general path reports it)
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mr = 0.0f;
+        bool finite = true;
+        for (uint32_t i = so[s]; i < so[s + 1]; i++) {
+            const float p[3] = {x[i], y[i], z[i]};
+            for (int k = 0; k < 3; k++) {
+                mn[k] = fminf(mn[k], p[k]);
+                mx[k] = fmaxf(mx[k], p[k]);
+                finite &= std::isfinite(p[k]);
+            }
+            mr = fmaxf(mr, radius[i]);
+            finite &= std::isfinite(radius[i]);
+        }
+        if (!finite || !small_grid(mn, mx, mr, probe, so[s + 1] - so[s], &grids[s])) return kNotSmall;
+        grids[s].atom_begin = so[s];
+        grids[s].sorted_base = so[s];
+        grids[s].cell_base = (uint32_t)total_cells;
+        total_cells += grids[s].n_cells;
+    }
+    const unsigned long long tail_begin = (total_cells + 1ull + 1023ull) & ~1023ull;
+
+    Lattice lat;
+    int rc = get_lattice(ctx, n_points, &lat);
+    if (rc) return rc;
+    // staging layout (16-byte aligned sections): status | grids | x | y | z | r | id | residue offsets
+    auto up = [](size_t v) { return (v + 15) & ~size_t(15); };
+    const size_t o_grid = 64, o_x = o_grid + S * sizeof(StructGrid), o_y = o_x + up(N * 4), o_z = o_y + up(N * 4),
+                 o_r = o_z + up(N * 4), o_id = o_r + up(N * 4), o_res = o_id + (id ? up(N * 8) : 0),
+                 in_bytes = o_res + (R ? up((R + 1) * 4) : 0);
+    const size_t o_oa = 0, o_or = up(N * 4), out_bytes = o_or + up(R * 4);
+    const size_t host_bytes = in_bytes + out_bytes;
+    if (host_bytes > ctx->h_small_cap) {
+        if (ctx->h_small) {
+            RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            RS_HIP(ctx, hipHostFree(ctx->h_small));
+            ctx->h_small = nullptr;
+            ctx->h_small_cap = 0;
+        }
+        RS_HIP(ctx, hipHostMalloc(&ctx->h_small, host_bytes * 2, hipHostMallocDefault));
+        ctx->h_small_cap = host_bytes * 2;
+    }
+    if ((rc = reserve(ctx, ctx->small_in, in_bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->small_out, out_bytes))) return rc;
+    if ((rc = reserve(ctx, ctx->sid_sorted, N * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->deferred_list, N * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->cell_of, N * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->rank_of, N * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->cells, (size_t)(tail_begin + 8) * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->sorted_xyzr, N * 16))) return rc;
+    if ((rc = reserve(ctx, ctx->sorted_orig, N * 4))) return rc;
+    if (id && (rc = reserve(ctx, ctx->sorted_id, N * 8))) return rc;
+
+    char *h = (char *)ctx->h_small;
+    BatchStatus stt{};
+    stt.total_cells = tail_begin;
+    stt.tail_cell_begin = tail_begin;
+    stt.tail_atom_base = (uint32_t)N;
+    std::memcpy(h, &stt, sizeof stt);
+    std::memcpy(h + o_grid, grids.data(), S * sizeof(StructGrid));
+    std::memcpy(h + o_x, x, N * 4);
+    std::memcpy(h + o_y, y, N * 4);
+    std::memcpy(h + o_z, z, N * 4);
+    std::memcpy(h + o_r, radius, N * 4);
+    if (id) std::memcpy(h + o_id, id, N * 8);
+    if (R) std::memcpy(h + o_res, ro, (R + 1) * 4);
+    hipStream_t st = ctx->stream;
+    char *d = (char *)ctx->small_in.p, *dout = (char *)ctx->small_out.p;
+    RS_HIP(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+
+    BatchView v{};
+    v.x = (const float *)(d + o_x); v.y = (const float *)(d + o_y); v.z = (const float *)(d + o_z);
+    v.radius = (const float *)(d + o_r);
+    v.id = id ? (const uint64_t *)(d + o_id) : nullptr;
+    v.residue_offsets = R ? (const uint32_t *)(d + o_res) : nullptr;
+    v.n_atoms = (uint32_t)N; v.n_structures = (uint32_t)S; v.n_residues = (uint32_t)R;
+    v.probe = probe;
+    v.grids = (StructGrid *)(d + o_grid);
+    v.status = (BatchStatus *)d;
+    v.sid_sorted = (uint32_t *)ctx->sid_sorted.p;
+    v.deferred_list = (uint32_t *)ctx->deferred_list.p;
+    v.cell_of = (uint32_t *)ctx->cell_of.p;
+    v.rank_of = (uint32_t *)ctx->rank_of.p;
+    v.cells = (uint32_t *)ctx->cells.p;
+    v.cell_capacity = tail_begin + 8;
+    v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
+    v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
+    v.sorted_id = id ? (uint64_t *)ctx->sorted_id.p : nullptr;
+    v.atom_sasa = (float *)(dout + o_oa);
+    v.residue_sasa = R ? (float *)(dout + o_or) : nullptr;
+    launch_sort_lds_single(v, st);
+    launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
+    launch_residue_sums(v, st);
+    char *hout = h + in_bytes;
+    RS_HIP(ctx, hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
+    RS_HIP(ctx, hipGetLastError());
+    RS_HIP(ctx, hipStreamSynchronize(st));
+    if (out_atom) std::memcpy(out_atom, hout + o_oa, N * 4);
+    if (R) std::memcpy(out_res, hout + o_or, R * 4);
+    return RSASA_OK;
+}
+
+}  // namespace
+
 int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float *y,
                                const float *z, const float *radius, const uint64_t *id,
                                const uint32_t *structure_offsets, size_t n_structures,
@@ -598,6 +763,12 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+    if (ctx->small_path) {
+        rc = run_small_host_batch(ctx, x, y, z, radius, id, structure_offsets, n_structures, probe_radius, n_points,
+                                  out_atom_sasa, want_res ? residue_offsets : nullptr, want_res ? n_residues : 0,
+                                  out_residue_sasa);
+        if (rc != kNotSmall) return rc;
+    }
 
     // Large batches are cut into sub-batches of whole structures (and whole residues) whose
     // host-to-device copies run on a second stream into a second set of input buffers while the

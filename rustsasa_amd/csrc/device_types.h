@@ -109,6 +109,7 @@ struct OcclusionTuning {
 void launch_grid_prepare(const BatchView &b, hipStream_t stream);
 void launch_sort_lds(const BatchView &b, hipStream_t stream);
 void launch_sort_tail(const BatchView &b, hipStream_t stream);
+void launch_sort_lds_single(const BatchView &b, hipStream_t stream);
 // Which atoms (cell-sorted positions) an occlusion launch covers: the tail's binning may still be
 // running on another stream while the LDS-binned structures are processed.
 enum OcclusionPart : uint32_t {

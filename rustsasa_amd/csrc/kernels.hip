@@ -491,6 +491,13 @@ void launch_sort_lds(const BatchView &b, hipStream_t stream)
     hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
 }
 
+// Small host-side batches (context.cpp, run_small_host_batch): the grids were computed on the
+// host and every structure is marked for the windowed LDS kernel.
+void launch_sort_lds_single(const BatchView &b, hipStream_t stream)
+{
+    if (b.n_structures) hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
+}
+
 // Batch-wide binning of the other structures (the tail).  Independent of launch_sort_lds: the
 // context runs it on a second stream, next to the LDS binning and the first occlusion launch.
 void launch_sort_tail(const BatchView &b, hipStream_t stream)

@@ -313,7 +313,8 @@ def test_full_proteome_properties(ctx):
                                  {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "7"},
                                  {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "1"},
                                  {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "3"},
-                                 {"RSASA_OVERLAP_TAIL": "1"}])
+                                 {"RSASA_OVERLAP_TAIL": "1"},
+                                 {"RSASA_SMALL_PATH": "0"}])
 def test_kernel_variants_agree(env, monkeypatch):
     """Every occlusion kernel variant / wave schedule gives bit-identical results."""
     import rustsasa_amd
@@ -514,3 +515,34 @@ def test_host_batch_pipelined_sub_batches(ctx):
         lo, hi = int(b.structure_offsets[s]), int(b.structure_offsets[s + 1])
         want = po.calculate_sasa_internal(*b.structure(int(s)), PROBE, 100, 8)
         assert np.array_equal(atom[lo:hi], want)
+
+
+def test_small_host_batches_take_the_short_path_and_agree(monkeypatch):
+    """Host batches of up to 32 768 atoms in up to 256 structures: the host computes the grids and
+    the device gets one upload, four launches and one download.  Same results as the general path,
+    including batches it has to hand back (empty structure, a grid too large for the LDS windows)."""
+    import rustsasa_amd
+    b = bw.synthetic_proteome(9, seed=77)
+    cut = int(np.searchsorted(b.structure_offsets, 30000, side="right")) - 1
+    so = b.structure_offsets[:cut + 1]
+    n = int(so[-1])
+    ro = b.residue_offsets[:int(np.searchsorted(b.residue_offsets, n, side="right"))]
+    args = (b.x[:n], b.y[:n], b.z[:n], b.radius[:n], b.ids[:n], so, PROBE, 100)
+    want = po.calculate_sasa_batch(b.x[:n], b.y[:n], b.z[:n], b.radius[:n], b.ids[:n], so, PROBE, 100, 8, threads=4)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RSASA_SMALL_PATH", flag)
+        with rustsasa_amd.Context(0) as c:
+            atom, res = c.calculate_sasa_batch(*args, residue_offsets=ro)
+            # an empty structure in the middle / a very elongated structure: general path either way
+            so2 = np.array([0, 100, 100, 300], np.uint32)
+            a2, _ = c.calculate_sasa_batch(b.x[:300], b.y[:300], b.z[:300], b.radius[:300], b.ids[:300], so2, PROBE, 100)
+            x3 = b.x[:400].copy()
+            x3[200:] += 30000.0
+            a3, _ = c.calculate_sasa_batch(x3, b.y[:400], b.z[:400], b.radius[:400], b.ids[:400],
+                                           np.array([0, 400], np.uint32), PROBE, 100)
+            outs.append((atom, res, a2, a3))
+    assert np.array_equal(outs[0][0], want) and np.array_equal(outs[1][0], want)
+    for u, v in zip(outs[0], outs[1]):
+        assert np.array_equal(u, v)
+    assert np.array_equal(outs[0][1], po.residue_sums(want, ro))
