@@ -546,3 +546,34 @@ def test_small_host_batches_take_the_short_path_and_agree(monkeypatch):
     for u, v in zip(outs[0], outs[1]):
         assert np.array_equal(u, v)
     assert np.array_equal(outs[0][1], po.residue_sums(want, ro))
+
+
+def test_geometry_stress(ctx):
+    """Awkward geometry for the run culling (which works in cell units with a rounding tolerance):
+    large coordinate offsets (coarse f32 spacing), flat and linear clouds, atoms on cell
+    boundaries, huge and tiny radii.  Host small path and device-resident path against the oracle."""
+    rng = np.random.default_rng(2024)
+    for trial in range(24):
+        n = int(rng.integers(2, 600))
+        shape = np.array([[30, 30, 30], [60, 60, 0.0], [200, 0.0, 0.0], [12, 12, 12]][trial % 4], float)
+        c = rng.uniform(0, 1, size=(n, 3)) * shape
+        if trial % 3 == 1:
+            c = np.round(c / 3.3) * 3.3          # many atoms exactly on cell-boundary-like positions
+        offset = float([0.0, 1.0e3, 1.0e5, -7.7e4][trial % 4 if trial >= 4 else 0])
+        c = (c + offset).astype(np.float32)
+        r = rng.uniform(0.5, 3.0 if trial % 5 else 6.0, size=n).astype(np.float32)
+        ids = np.arange(n, dtype=np.uint64)
+        probe = float(rng.choice([0.0, 1.4, 3.0]))
+        x, y, z = c[:, 0].copy(), c[:, 1].copy(), c[:, 2].copy()
+        want = po.calculate_sasa_internal(x, y, z, r, ids, probe, 100, 8)
+        got = ctx.calculate_sasa_soa(x, y, z, r, ids, probe, 100)
+        assert np.array_equal(got, want), ("host path", trial, n, offset, probe)
+        b = bw.Batch(x, y, z, r, ids, np.array([0, n], np.uint32), np.array([0, n], np.uint32))
+        import torch
+        dev = torch.device("cuda:0")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        ctx.enqueue_device(t(x), t(y), t(z), t(r), t(ids.view(np.int64)), b.structure_offsets, out, None, None, None,
+                           probe, 100, stream=torch.cuda.current_stream().cuda_stream)
+        ctx.wait()
+        assert np.array_equal(out.cpu().numpy(), want), ("device path", trial, n, offset, probe)
