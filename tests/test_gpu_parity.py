@@ -577,3 +577,31 @@ def test_geometry_stress(ctx):
                            probe, 100, stream=torch.cuda.current_stream().cuda_stream)
         ctx.wait()
         assert np.array_equal(out.cpu().numpy(), want), ("device path", trial, n, offset, probe)
+
+
+def test_duplicate_ids_in_device_batches():
+    """The id rule on the device-resident path: heavy duplication, sparse duplication, all-equal ids,
+    ids that differ in the high word only, and a -0.0 radius must all match the oracle."""
+    import rustsasa_amd
+    rng = np.random.default_rng(5)
+    b = bw.synthetic_proteome(40, seed=13)
+    n = b.n_atoms
+    variants = {
+        "triples": (np.arange(n, dtype=np.uint64) // 3),
+        "sparse": np.where(rng.random(n) < 0.01, np.uint64(7), np.arange(n, dtype=np.uint64) + 100),
+        "all_equal": np.full(n, 42, np.uint64),
+        "high_word_only": (np.arange(n, dtype=np.uint64) % 5) << np.uint64(40),
+    }
+    with rustsasa_amd.Context(0) as c:
+        for name, ids in variants.items():
+            bb = bw.Batch(b.x, b.y, b.z, b.radius, ids.astype(np.uint64), b.structure_offsets, b.residue_offsets)
+            atom, _, k = _device_run(c, bb, want_res=False)
+            want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, bb.ids, b.structure_offsets, PROBE, 100, 8, threads=8)
+            assert np.array_equal(atom, want), name
+        # -0.0 as a radius
+        r2 = b.radius.copy()
+        r2[5] = np.float32(-0.0)
+        bb = bw.Batch(b.x, b.y, b.z, r2, variants["triples"].astype(np.uint64), b.structure_offsets, b.residue_offsets)
+        atom, _, _ = _device_run(c, bb, want_res=False)
+        want = po.calculate_sasa_batch(b.x, b.y, b.z, r2, bb.ids, b.structure_offsets, PROBE, 100, 8, threads=8)
+        assert np.array_equal(atom, want)
