@@ -190,9 +190,9 @@ def synthetic_uniform(n_atoms=1_000_000, seed=5, density=0.05, jitter=0.7) -> Ba
                  np.ascontiguousarray(xyz[:, 2]), r, ids, np.array([0, n_atoms], np.uint32), res)
 
 
-def shard(batch: Batch, rank: int, world: int) -> Batch:
-    """Structures rank, rank + world, ... (sizes are i.i.d., so shards are balanced)."""
-    sel = np.arange(rank, batch.n_structures, world)
+def select(batch: Batch, sel) -> Batch:
+    """The structures `sel` (indices, in that order) as a batch of their own."""
+    sel = np.asarray(sel, np.int64)
     so = batch.structure_offsets.astype(np.int64)
     ro = batch.residue_offsets.astype(np.int64)
     idx, new_so, new_ro = [], [0], [0]
@@ -205,3 +205,24 @@ def shard(batch: Batch, rank: int, world: int) -> Batch:
     idx = np.concatenate(idx) if idx else np.zeros(0, np.int64)
     return Batch(batch.x[idx], batch.y[idx], batch.z[idx], batch.radius[idx], batch.ids[idx],
                  np.array(new_so, np.uint32), np.array(new_ro, np.uint32))
+
+
+def shard(batch: Batch, rank: int, world: int) -> Batch:
+    """Structures rank, rank + world, ... (sizes are i.i.d., so shards are balanced)."""
+    return select(batch, np.arange(rank, batch.n_structures, world))
+
+
+def shard_largest_first(sizes, world: int):
+    """Strong-scaling partition of SURVEY 8e: structures sorted by atom count, largest first, each
+    handed to the rank with the fewest atoms so far (what a dynamic largest-first queue converges
+    to when the cost of a structure is its atom count).  Returns one index array per rank, each
+    in descending size order; together they are a partition of range(len(sizes))."""
+    sizes = np.asarray(sizes, np.int64)
+    order = np.argsort(-sizes, kind="stable")
+    load = np.zeros(world, np.int64)
+    parts = [[] for _ in range(world)]
+    for s in order:
+        r = int(np.argmin(load))  # ties: lowest rank
+        parts[r].append(int(s))
+        load[r] += sizes[s]
+    return [np.array(p, np.int64) for p in parts]

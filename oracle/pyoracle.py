@@ -46,6 +46,9 @@ def _load():
         lib.oracle_calculate_sasa_internal.argtypes = [fp, fp, fp, fp, u64p, C.c_size_t, C.c_float,
                                                        C.c_size_t, C.c_int, fp, u32p, u32p]
         lib.oracle_calculate_sasa_internal.restype = C.c_int
+        lib.oracle_calculate_sasa_internal_mt.argtypes = [fp, fp, fp, fp, u64p, C.c_size_t, C.c_float,
+                                                          C.c_size_t, C.c_int, C.c_int, fp, u32p, u32p]
+        lib.oracle_calculate_sasa_internal_mt.restype = C.c_int
         lib.oracle_calculate_sasa_batch.argtypes = [fp, fp, fp, fp, u64p, u32p, C.c_size_t,
                                                     C.c_float, C.c_size_t, C.c_int, C.c_int, fp]
         lib.oracle_calculate_sasa_batch.restype = C.c_int
@@ -80,17 +83,18 @@ def sphere_points(n_points: int):
 
 
 def calculate_sasa_internal(x, y, z, radius, ids=None, probe_radius=1.4, n_points=100,
-                            simd_width=8, return_details=False):
-    """Restatement of calculate_sasa_internal (reference src/lib.rs:249-298)."""
+                            simd_width=8, return_details=False, threads=1):
+    """Restatement of calculate_sasa_internal (reference src/lib.rs:249-298); `threads` as there:
+    1 = sequential over the atoms, otherwise parallel (0 = all cores)."""
     x, y, z, radius = map(_f32, (x, y, z, radius))
     n = x.shape[0]
     ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
     out = np.zeros(n, np.float32)
     pts = np.zeros(n, np.uint32)
     k = np.zeros(n, np.uint32)
-    rc = _load().oracle_calculate_sasa_internal(
+    rc = _load().oracle_calculate_sasa_internal_mt(
         _ptr(x, C.c_float), _ptr(y, C.c_float), _ptr(z, C.c_float), _ptr(radius, C.c_float),
-        _ptr(ids_a, C.c_uint64), n, np.float32(probe_radius), n_points, simd_width,
+        _ptr(ids_a, C.c_uint64), n, np.float32(probe_radius), n_points, simd_width, threads,
         _ptr(out, C.c_float), _ptr(pts, C.c_uint32), _ptr(k, C.c_uint32))
     if rc != 0:
         raise RuntimeError(f"oracle_calculate_sasa_internal failed ({rc})")

@@ -588,7 +588,7 @@ static kernel_fn pick_kernel(int simd_width)
 static int calculate_with_lattice(const atoms_t *a, float probe, size_t n_points,
                                   const float *spx, const float *spy, const float *spz,
                                   kernel_fn kern, float *out_sasa, uint32_t *out_points,
-                                  uint32_t *out_k)
+                                  uint32_t *out_k, int atom_threads)
 {
     size_t n = a->n;
     if (n == 0)
@@ -600,7 +600,10 @@ static int calculate_with_lattice(const atoms_t *a, float probe, size_t n_points
     oracle_neighbor_t *slab = NULL;
     if (precompute_neighbors(a, probe, max_radii, &lists, &slab))       /* lib.rs:264 */
         return -1;
-    for (size_t i = 0; i < n; i++) {                                     /* lib.rs:278-283 */
+    /* lib.rs:278-290: sequential when threads == 1, otherwise a parallel map over the atoms
+     * (rayon par_iter there, OpenMP here); every atom's value is independent of the others */
+#pragma omp parallel for schedule(dynamic, 512) num_threads(atom_threads) if (atom_threads > 1)
+    for (long i = 0; i < (long)n; i++) {                                 /* lib.rs:278-283 */
         out_sasa[i] = kern(a, i, &lists[i], spx, spy, spz, n_points, probe,
                            out_points ? &out_points[i] : NULL);
         if (out_k)
@@ -615,6 +618,18 @@ int oracle_calculate_sasa_internal(const float *x, const float *y, const float *
                                    float probe_radius, size_t n_points, int simd_width,
                                    float *out_sasa, uint32_t *out_points, uint32_t *out_k)
 {
+    return oracle_calculate_sasa_internal_mt(x, y, z, radius, id, n, probe_radius, n_points,
+                                             simd_width, 1, out_sasa, out_points, out_k);
+}
+
+int oracle_calculate_sasa_internal_mt(const float *x, const float *y, const float *z,
+                                      const float *radius, const uint64_t *id, size_t n,
+                                      float probe_radius, size_t n_points, int simd_width,
+                                      int threads, float *out_sasa, uint32_t *out_points,
+                                      uint32_t *out_k)
+{
+    if (threads < 1)
+        threads = oracle_max_threads();
     kernel_fn kern = pick_kernel(simd_width);
     if (!kern)
         return -1;
@@ -624,7 +639,7 @@ int oracle_calculate_sasa_internal(const float *x, const float *y, const float *
         return -1;
     oracle_generate_sphere_points(n_points, sp, sp + n_points, sp + 2 * n_points); /* :257 */
     int rc = calculate_with_lattice(&a, probe_radius, n_points, sp, sp + n_points,
-                                    sp + 2 * n_points, kern, out_sasa, out_points, out_k);
+                                    sp + 2 * n_points, kern, out_sasa, out_points, out_k, threads);
     free(sp);
     return rc;
 }
@@ -655,7 +670,7 @@ int oracle_calculate_sasa_batch(const float *x, const float *y, const float *z,
         }
         oracle_generate_sphere_points(n_points, sp, sp + n_points, sp + 2 * n_points);
         if (calculate_with_lattice(&a, probe_radius, n_points, sp, sp + n_points,
-                                   sp + 2 * n_points, kern, out_sasa + b, NULL, NULL)) {
+                                   sp + 2 * n_points, kern, out_sasa + b, NULL, NULL, 1)) {
 #pragma omp atomic write
             failed = 1;
         }

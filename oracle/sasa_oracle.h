@@ -66,6 +66,15 @@ int oracle_calculate_sasa_internal(const float *x, const float *y, const float *
                                    float probe_radius, size_t n_points, int simd_width,
                                    float *out_sasa, uint32_t *out_points, uint32_t *out_k);
 
+/* The same with the reference's `threads` argument (src/lib.rs:278-290): 1 = sequential map over
+ * the atoms, anything else a parallel map (rayon there, OpenMP here; < 1 = all cores).  Results
+ * do not depend on it. */
+int oracle_calculate_sasa_internal_mt(const float *x, const float *y, const float *z,
+                                      const float *radius, const uint64_t *id, size_t n,
+                                      float probe_radius, size_t n_points, int simd_width,
+                                      int threads, float *out_sasa, uint32_t *out_points,
+                                      uint32_t *out_k);
+
 /* Directory mode of the reference (src/main.rs:375,439): independent
  * structures, each computed sequentially, spread over `threads` OpenMP
  * threads.  offsets has n_structures + 1 entries into the concatenated SoA. */

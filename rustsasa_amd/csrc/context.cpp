@@ -87,8 +87,13 @@ struct rsasa_context {
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
     DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res;  // second input slot of the pipelined host-buffer path
+    DeviceBuffer atom_sasa2, out_res2;            // second output slot of the same path
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
+    hipStream_t d2h_stream = nullptr;             // D2H of the previous sub-batch's results meanwhile
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    hipEvent_t ev_d2h[2] = {nullptr, nullptr};    // output slot k has been copied out
+    void *h_out[2] = {nullptr, nullptr};          // pinned staging for results whose destination is pageable
+    size_t h_out_cap[2] = {0, 0};
     DeviceBuffer small_in, small_out;          // small host batches: one upload / one download buffer
     void *h_small = nullptr;                   // pinned staging of the same layout
     size_t h_small_cap = 0;
@@ -109,6 +114,9 @@ namespace {
 int fail(rsasa_context *ctx, int code, const char *what, hipError_t e = hipSuccess)
 {
     if (ctx) {
+        // several threads may share a context (host_api.cpp runs two workers on one): the message
+        // is written and read under the context's (recursive) mutex
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
         ctx->last_error = what;
         if (e != hipSuccess) {
             ctx->last_error += ": ";
@@ -117,6 +125,29 @@ int fail(rsasa_context *ctx, int code, const char *what, hipError_t e = hipSucce
     }
     return code;
 }
+
+// Entry points run on the context's device and leave the calling thread's current device as
+// they found it (a host program with several GPUs - or torch - keeps its own current device).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        err = prev == device ? hipSuccess : hipSetDevice(device);
+        if (prev == device) prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define RS_DEVICE(ctx)                                                        \
+    DeviceGuard device_guard_((ctx)->device);                                 \
+    if (device_guard_.err != hipSuccess)                                      \
+        return fail((ctx), RSASA_ERR_HIP, "hipSetDevice", device_guard_.err)
 
 #define RS_HIP(ctx, expr)                                                           \
     do {                                                                            \
@@ -164,6 +195,18 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
     const auto key = std::make_pair(n_points, ctx->simd_width);
     auto it = ctx->lattices.find(key);
     if (it == ctx->lattices.end()) {
+        // the cache holds the few point counts a program uses; a sweep over many counts must not
+        // pin 28 bytes per point per count forever
+        size_t cached_bytes = 0;
+        for (const auto &kv : ctx->lattices) cached_bytes += 7 * sizeof(float) * (size_t)kv.second.padded;
+        if (ctx->lattices.size() >= 16 || cached_bytes > (64u << 20)) {
+            RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->pending.active && ctx->pending.stream != ctx->stream)
+                RS_HIP(ctx, hipStreamSynchronize(ctx->pending.stream));
+            for (auto &kv : ctx->lattices)
+                if (kv.second.d) (void)hipFree(kv.second.d);
+            ctx->lattices.clear();
+        }
         const uint32_t padded = (uint32_t)((n_points + 63) / 64 * 64);
         std::vector<float> h(7 * (size_t)padded, 0.0f);  // x | y | z | (x, y, z, 0) records
         generate_sphere_points(n_points, h.data(), h.data() + padded, h.data() + 2 * (size_t)padded);
@@ -244,7 +287,8 @@ int enqueue_pending(rsasa_context *ctx)
     if ((rc = reserve(ctx, ctx->deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rank_of, std::max<size_t>(N, 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1) * 4))) return rc;
+    // + 1 end marker, + 3: k_zero_cells / k_scan_* access whole 16-byte vectors up to the end marker
+    if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1 + 3) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->scan_sums, kScanBlocks * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
@@ -425,14 +469,17 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     rsasa_context *ctx = new (std::nothrow) rsasa_context();
     if (!ctx) return RSASA_ERR_OUT_OF_MEMORY;
     ctx->device = device;
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard guard(device);
+    hipError_t e = guard.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming);
     if (e == hipSuccess)
         e = hipHostMalloc((void **)&ctx->h_status, sizeof(BatchStatus), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -442,7 +489,9 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     std::memset(ctx->h_status, 0, sizeof(BatchStatus));
     if (const char *v = std::getenv("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
     if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
+#ifdef RSASA_ABLATE  // timing-ablation builds only (make ablate): the shipped library has no wrong-results switch
     if (const char *v = std::getenv("RSASA_DEBUG_STOP")) ctx->tuning.debug_stop = (uint32_t)std::atoi(v);
+#endif
     if (const char *v = std::getenv("RSASA_OVERLAP_TAIL")) ctx->overlap_tail = std::atoi(v) != 0;
     if (const char *v = std::getenv("RSASA_SMALL_PATH")) ctx->small_path = std::atoi(v) != 0;
     *out_ctx = ctx;
@@ -452,13 +501,15 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
 int rsasa_context_destroy(rsasa_context_t *ctx)
 {
     if (!ctx) return RSASA_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
+                            &ctx->atom_sasa2, &ctx->out_res2,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
                             &ctx->tr_id, &ctx->tr_res})
         release(*b);
@@ -470,7 +521,12 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 2; i++)
         if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_d2h[i]) (void)hipEventDestroy(ctx->ev_d2h[i]);
+        if (ctx->h_out[i]) (void)hipHostFree(ctx->h_out[i]);
+    }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -482,7 +538,14 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
 
 const char *rsasa_context_last_error(const rsasa_context_t *ctx)
 {
-    return ctx ? ctx->last_error.c_str() : "";
+    if (!ctx) return "";
+    // a copy per calling thread, taken under the lock: another thread's failure cannot change
+    // (or free) the string while this one reads it; valid until this thread's next call
+    static thread_local std::string copy;
+    rsasa_context *c = const_cast<rsasa_context *>(ctx);
+    std::lock_guard<std::recursive_mutex> lk(c->mu);
+    copy = c->last_error;
+    return copy.c_str();
 }
 
 int rsasa_context_set_simd_width(rsasa_context_t *ctx, int w)
@@ -549,7 +612,7 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
     if (batch->n_residues && batch->residue_offsets && !batch->out_residue_sasa)
         return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "out_residue_sasa is NULL");
 
-    RS_HIP(ctx, hipSetDevice(ctx->device));
+    RS_DEVICE(ctx);
     if (ctx->pending.active) {
         rc = wait_pending(ctx);
         if (rc) return rc;
@@ -569,7 +632,7 @@ int rsasa_batch_wait(rsasa_context_t *ctx)
     int rc = resolve_ctx(ctx);
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    RS_HIP(ctx, hipSetDevice(ctx->device));
+    RS_DEVICE(ctx);
     return wait_pending(ctx);
 }
 
@@ -761,7 +824,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    RS_HIP(ctx, hipSetDevice(ctx->device));
+    RS_DEVICE(ctx);
     if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
     if (ctx->small_path) {
         rc = run_small_host_batch(ctx, x, y, z, radius, id, structure_offsets, n_structures, probe_radius, n_points,
@@ -801,9 +864,11 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         }
     }
     const bool piped = cut.size() > 2;
+    const size_t n_sub = cut.size() - 1;
     DeviceBuffer *bx[2] = {&ctx->in_x, &ctx->in2_x}, *by[2] = {&ctx->in_y, &ctx->in2_y};
     DeviceBuffer *bz[2] = {&ctx->in_z, &ctx->in2_z}, *br[2] = {&ctx->in_r, &ctx->in2_r};
     DeviceBuffer *bi[2] = {&ctx->in_id, &ctx->in2_id}, *bo[2] = {&ctx->in_res, &ctx->in2_res};
+    DeviceBuffer *oa[2] = {&ctx->atom_sasa, &ctx->atom_sasa2}, *orr[2] = {&ctx->out_res, &ctx->out_res2};
     for (int k = 0; k < (piped ? 2 : 1); k++) {
         if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
@@ -811,9 +876,36 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
         if (id && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
         if (want_res && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
+        if ((rc = reserve(ctx, *oa[k], max_atoms * 4))) return rc;
+        if (want_res && (rc = reserve(ctx, *orr[k], max_res * 4))) return rc;
     }
-    if ((rc = reserve(ctx, ctx->atom_sasa, max_atoms * 4))) return rc;
-    if (want_res && (rc = reserve(ctx, ctx->out_res, max_res * 4))) return rc;
+
+    // Results leave on their own stream while the next sub-batch computes.  A destination in
+    // pinned (page-locked) host memory takes the copy directly; a pageable one gets it through
+    // pinned staging, moved to its place by this thread once the copy has landed.
+    auto is_pinned = [](const void *p) {
+        hipPointerAttribute_t at{};
+        if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return at.type == hipMemoryTypeHost;
+    };
+    const bool atoms_direct = !out_atom_sasa || is_pinned(out_atom_sasa);
+    const bool res_direct = !want_res || is_pinned(out_residue_sasa);
+    const size_t stage_atoms = (out_atom_sasa && !atoms_direct) ? max_atoms * 4 : 0;
+    const size_t stage_bytes = stage_atoms + ((want_res && !res_direct) ? max_res * 4 : 0);
+    for (int k = 0; k < (piped ? 2 : 1) && stage_bytes; k++) {
+        if (stage_bytes <= ctx->h_out_cap[k]) continue;
+        if (ctx->h_out[k]) {
+            RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
+            RS_HIP(ctx, hipHostFree(ctx->h_out[k]));
+            ctx->h_out[k] = nullptr;
+            ctx->h_out_cap[k] = 0;
+        }
+        RS_HIP(ctx, hipHostMalloc(&ctx->h_out[k], stage_bytes + stage_bytes / 4, hipHostMallocDefault));
+        ctx->h_out_cap[k] = stage_bytes + stage_bytes / 4;
+    }
 
     // host copies of the rebased offsets stay alive until their sub-batch has been waited for
     std::vector<uint32_t> so[2], ro[2];
@@ -837,15 +929,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         }
         return RSASA_OK;
     };
-
-    hipStream_t st = ctx->stream, cp = piped ? ctx->copy_stream : ctx->stream;
-    if ((rc = upload(0, cp))) return rc;
-    if (piped) RS_HIP(ctx, hipEventRecord(ctx->ev_copy[0], cp));
-    for (size_t c = 0; c + 1 < cut.size(); c++) {
+    auto enqueue = [&](size_t c) -> int {
         const int k = (int)(c & 1);
-        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
-        const size_t r0 = res_cut[c], nr = want_res ? res_cut[c + 1] - r0 : 0;
-        if (piped) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
+        const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
+        const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
         rsasa_device_batch_t bt{};
         bt.x = (const float *)bx[k]->p;
         bt.y = (const float *)by[k]->p;
@@ -857,24 +944,70 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         bt.n_atoms = na;
         bt.residue_offsets = nr ? (const uint32_t *)bo[k]->p : nullptr;
         bt.n_residues = nr;
-        bt.out_atom_sasa = (float *)ctx->atom_sasa.p;
-        bt.out_residue_sasa = nr ? (float *)ctx->out_res.p : nullptr;
+        bt.out_atom_sasa = (float *)oa[k]->p;
+        bt.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
         bt.out_neighbor_counts = nullptr;
-        const bool run = na || nr;
-        if (run && (rc = rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr))) return rc;
-        // The kernels of sub-batch c are queued; now feed the next one.  (A copy from pageable
-        // memory keeps this thread busy, so it has to come after the enqueue to overlap.)  Slot
-        // k ^ 1 was last read by sub-batch c - 1, which has been waited for.
-        if (piped && c + 2 < cut.size()) {
+        if (!(na || nr)) return RSASA_OK;
+        return rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr);
+    };
+    // staged results of output slot k that still have to be moved to the caller's arrays
+    struct Staged { bool active = false; size_t a0 = 0, na = 0, r0 = 0, nr = 0; } staged[2];
+    auto drain = [&](int k) -> int {
+        if (!staged[k].active) return RSASA_OK;
+        RS_HIP(ctx, hipEventSynchronize(ctx->ev_d2h[k]));
+        const char *h = (const char *)ctx->h_out[k];
+        if (out_atom_sasa && !atoms_direct && staged[k].na)
+            std::memcpy(out_atom_sasa + staged[k].a0, h, staged[k].na * 4);
+        if (want_res && !res_direct && staged[k].nr)
+            std::memcpy(out_residue_sasa + staged[k].r0, h + stage_atoms, staged[k].nr * 4);
+        staged[k].active = false;
+        return RSASA_OK;
+    };
+
+    // Three streams: copy-in (sub-batch c + 1), compute (c), copy-out (c - 1).  The host waits for
+    // sub-batch c (its status decides whether it has to run again with a larger cell array),
+    // queues the kernels of c + 1 right away and only then starts c's copy-out.
+    hipStream_t st = ctx->stream, cp = piped ? ctx->copy_stream : ctx->stream, dn = ctx->d2h_stream;
+    if ((rc = upload(0, cp))) return rc;
+    if (piped) {
+        RS_HIP(ctx, hipEventRecord(ctx->ev_copy[0], cp));
+        RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[0], 0));
+    }
+    if ((rc = enqueue(0))) return rc;
+    bool d2h_used[2] = {false, false};
+    for (size_t c = 0; c < n_sub; c++) {
+        const int k = (int)(c & 1);
+        const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
+        const size_t r0 = res_cut[c], nr = want_res ? res_cut[c + 1] - r0 : 0;
+        // feed the next sub-batch: input slot k ^ 1 was last read by sub-batch c - 1 (waited for).
+        // (A copy from pageable memory keeps this thread busy, so it comes after c's enqueue.)
+        if (c + 1 < n_sub) {
             if ((rc = upload(c + 1, cp))) return rc;
             RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k ^ 1], cp));
         }
-        if (run && (rc = rsasa_batch_wait(ctx))) return rc;
+        if ((na || nr) && (rc = rsasa_batch_wait(ctx))) return rc;
+        if (c + 1 < n_sub) {
+            RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k ^ 1], 0));
+            // output slot k ^ 1 must have left the device (sub-batch c - 1's copy-out)
+            if (d2h_used[k ^ 1]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k ^ 1], 0));
+            if ((rc = enqueue(c + 1))) return rc;
+        }
+        if ((rc = drain(k))) return rc;  // staging slot k still holds sub-batch c - 2
+        char *h = (char *)ctx->h_out[k];
         if (out_atom_sasa && na)
-            RS_HIP(ctx, hipMemcpy(out_atom_sasa + a0, ctx->atom_sasa.p, na * 4, hipMemcpyDeviceToHost));
+            RS_HIP(ctx, hipMemcpyAsync(atoms_direct ? (void *)(out_atom_sasa + a0) : (void *)h, oa[k]->p, na * 4,
+                                       hipMemcpyDeviceToHost, dn));
         if (nr)
-            RS_HIP(ctx, hipMemcpy(out_residue_sasa + r0, ctx->out_res.p, nr * 4, hipMemcpyDeviceToHost));
+            RS_HIP(ctx, hipMemcpyAsync(res_direct ? (void *)(out_residue_sasa + r0) : (void *)(h + stage_atoms),
+                                       orr[k]->p, nr * 4, hipMemcpyDeviceToHost, dn));
+        RS_HIP(ctx, hipEventRecord(ctx->ev_d2h[k], dn));
+        d2h_used[k] = true;
+        staged[k].active = stage_bytes != 0;
+        staged[k].a0 = a0; staged[k].na = na; staged[k].r0 = r0; staged[k].nr = nr;
     }
+    if ((rc = drain(0))) return rc;
+    if ((rc = drain(1))) return rc;
+    RS_HIP(ctx, hipStreamSynchronize(dn));
     return RSASA_OK;
 }
 
@@ -939,7 +1072,7 @@ int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size
                 return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets must be non-decreasing");
     }
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    RS_HIP(ctx, hipSetDevice(ctx->device));
+    RS_DEVICE(ctx);
     if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
     hipStream_t st = ctx->stream;
     // topology columns once
@@ -951,12 +1084,17 @@ int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size
     if (want_res)
         RS_HIP(ctx, hipMemcpyAsync(ctx->tr_res.p, residue_offsets, (n_residues + 1) * 4,
                                    hipMemcpyHostToDevice, st));
+    // Offsets that cover the atoms exactly tile over the frames as they are; otherwise every frame
+    // gets one more entry (k_expand_frames) and one gap "residue" whose sum is not copied out.
+    const bool res_exact = want_res && residue_offsets[0] == 0 && residue_offsets[n_residues] == n_atoms;
+    const size_t res_stride = want_res ? (res_exact ? n_residues : n_residues + 1) : 0;
     // frames in chunks of at most ~32 M atoms (32-bit indices, bounded workspace)
     const size_t chunk_frames = std::max<size_t>(1, std::min<size_t>(n_frames, (32u << 20) / n_atoms));
     std::vector<uint32_t> s_off(chunk_frames + 1);
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk_frames) {
         const size_t nf = std::min(chunk_frames, n_frames - f0);
-        const size_t N = nf * n_atoms, R = want_res ? nf * n_residues : 0;
+        const size_t N = nf * n_atoms, R = nf * res_stride;
+        if (R >= 0xFFFFFFF0ull) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "trajectory too large for 32-bit indices");
         if ((rc = reserve(ctx, ctx->tr_xyz, N * 12))) return rc;
         if ((rc = reserve(ctx, ctx->in_x, N * 4))) return rc;
         if ((rc = reserve(ctx, ctx->in_y, N * 4))) return rc;
@@ -972,7 +1110,7 @@ int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size
         launch_expand_frames((const float *)ctx->tr_xyz.p, (const float *)ctx->tr_r.p,
                              id ? (const uint64_t *)ctx->tr_id.p : nullptr,
                              want_res ? (const uint32_t *)ctx->tr_res.p : nullptr, (uint32_t)n_atoms,
-                             (uint32_t)nf, (uint32_t)n_residues, (float *)ctx->in_x.p, (float *)ctx->in_y.p,
+                             (uint32_t)nf, (uint32_t)res_stride, (float *)ctx->in_x.p, (float *)ctx->in_y.p,
                              (float *)ctx->in_z.p, (float *)ctx->in_r.p, (uint64_t *)ctx->in_id.p,
                              (uint32_t *)ctx->in_res.p, st);
         for (size_t f = 0; f <= nf; f++) s_off[f] = (uint32_t)(f * n_atoms);
@@ -993,9 +1131,12 @@ int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size
         if ((rc = rsasa_batch_wait(ctx))) return rc;
         if (out_atom_sasa)
             RS_HIP(ctx, hipMemcpy(out_atom_sasa + f0 * n_atoms, ctx->atom_sasa.p, N * 4, hipMemcpyDeviceToHost));
-        if (want_res)
+        if (want_res && res_exact)
             RS_HIP(ctx, hipMemcpy(out_residue_sasa + f0 * n_residues, ctx->out_res.p, R * 4,
                                   hipMemcpyDeviceToHost));
+        else if (want_res)  // n_residues of every res_stride sums: the gap entries stay behind
+            RS_HIP(ctx, hipMemcpy2D(out_residue_sasa + f0 * n_residues, n_residues * 4, ctx->out_res.p,
+                                    res_stride * 4, n_residues * 4, nf, hipMemcpyDeviceToHost));
     }
     return RSASA_OK;
 }
@@ -1014,7 +1155,7 @@ int rsasa_segment_sums(rsasa_context_t *ctx, const float *values, size_t n_value
         if (offsets[k] > offsets[k + 1])
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    RS_HIP(ctx, hipSetDevice(ctx->device));
+    RS_DEVICE(ctx);
     if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
     if ((rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(n_values, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->in_res, (n_segments + 1) * 4))) return rc;

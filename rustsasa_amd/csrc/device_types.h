@@ -121,7 +121,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
                       OcclusionPart part, hipStream_t stream);
 void launch_residue_sums(const BatchView &b, hipStream_t stream);
 void launch_expand_frames(const float *xyz, const float *radius, const uint64_t *id,
-                          const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t n_res,
+                          const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t res_stride,
                           float *x, float *y, float *z, float *r, uint64_t *id_out,
                           uint32_t *res_out, hipStream_t stream);
 

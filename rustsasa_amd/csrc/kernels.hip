@@ -513,13 +513,18 @@ void launch_sort_tail(const BatchView &b, hipStream_t stream)
 }
 
 // Trajectory frames: xyz is frame-major [n_frames][n_atoms][3] (what MD readers hand over);
-// radii, ids and residue offsets are given once and tiled over the frames.
+// radii, ids and residue offsets are given once and tiled over the frames.  `res_stride` entries
+// of res_out per frame: n_res when the residues cover the atoms exactly (a frame's last residue
+// ends where the next frame's first begins), n_res + 1 otherwise - the extra entry closes the
+// frame's last residue, and the "residue" between it and the next frame's first offset collects the
+// uncovered atoms (the caller skips it when copying the sums out).
 __global__ __launch_bounds__(256) void k_expand_frames(const float *xyz, const float *radius,
                                                        const uint64_t *id, const uint32_t *res_off,
                                                        uint32_t n_atoms, uint32_t n_frames,
-                                                       uint32_t n_res, float *x, float *y, float *z,
+                                                       uint32_t res_stride, float *x, float *y, float *z,
                                                        float *r, uint64_t *id_out, uint32_t *res_out)
 {
+    const uint32_t n_res = res_stride;
     const uint64_t total = (uint64_t)n_atoms * n_frames;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
@@ -538,13 +543,13 @@ __global__ __launch_bounds__(256) void k_expand_frames(const float *xyz, const f
 }
 
 void launch_expand_frames(const float *xyz, const float *radius, const uint64_t *id,
-                          const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t n_res,
+                          const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t res_stride,
                           float *x, float *y, float *z, float *r, uint64_t *id_out,
                           uint32_t *res_out, hipStream_t stream)
 {
-    const uint64_t n = std::max<uint64_t>((uint64_t)n_atoms * n_frames, (uint64_t)n_res * n_frames + 1);
+    const uint64_t n = std::max<uint64_t>((uint64_t)n_atoms * n_frames, (uint64_t)res_stride * n_frames + 1);
     hipLaunchKernelGGL(k_expand_frames, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, xyz,
-                       radius, id, res_off, n_atoms, n_frames, n_res, x, y, z, r, id_out, res_out);
+                       radius, id, res_off, n_atoms, n_frames, res_stride, x, y, z, r, id_out, res_out);
 }
 
 void launch_residue_sums(const BatchView &b, hipStream_t stream)

@@ -34,6 +34,37 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+def _columns(x, y, z, radius, ids, n_expected=None):
+    """The SoA columns as contiguous arrays of one common length (the C side sizes every copy from
+    the offsets it is given, so a short column would be read past its end)."""
+    x, y, z, radius = map(_f32, (x, y, z, radius))
+    ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+    n = x.shape[0]
+    for name, a in (("x", x), ("y", y), ("z", z), ("radius", radius), ("ids", ids)):
+        if a is not None and (a.ndim != 1 or a.shape[0] != n):
+            raise ValueError(f"{name} must be a 1-D array of {n} entries (the length of x)")
+    if n_expected is not None and n != n_expected:
+        raise ValueError(f"the offsets cover {n_expected} atoms but the columns hold {n}")
+    return x, y, z, radius, ids
+
+
+def _offsets(name, off):
+    off = np.ascontiguousarray(off, dtype=np.uint32)
+    if off.ndim != 1 or off.shape[0] < 1:
+        raise ValueError(f"{name} must be a 1-D array of at least one entry")
+    return off
+
+
+def _out_buffer(name, buf, n):
+    """A caller-provided output array (e.g. pinned host memory) or a fresh one."""
+    if buf is None:
+        return np.zeros(n, np.float32)
+    if not (isinstance(buf, np.ndarray) and buf.dtype == np.float32 and buf.ndim == 1 and
+            buf.shape[0] == n and buf.flags["C_CONTIGUOUS"] and buf.flags["WRITEABLE"]):
+        raise ValueError(f"{name} must be a writeable contiguous float32 array of {n} entries")
+    return buf
+
+
 class Context:
     """One GPU, one HIP stream, one growable HBM workspace (rsasa_context_t)."""
 
@@ -82,8 +113,7 @@ class Context:
 
     def calculate_sasa_soa(self, x, y, z, radius, ids=None, probe_radius: float = 1.4,
                            n_points: int = 100) -> np.ndarray:
-        x, y, z, radius = map(_f32, (x, y, z, radius))
-        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        x, y, z, radius, ids = _columns(x, y, z, radius, ids)
         out = np.zeros(x.shape[0], np.float32)
         self._check(self._lib.rsasa_calculate_sasa_soa(
             self._h, ptr(x), ptr(y), ptr(z), ptr(radius), ptr(ids), x.shape[0], probe_radius,
@@ -93,18 +123,22 @@ class Context:
     # ---- many structures, host buffers -----------------------------------
     def calculate_sasa_batch(self, x, y, z, radius, ids, structure_offsets,
                              probe_radius: float = 1.4, n_points: int = 100,
-                             residue_offsets=None, want_atoms: bool = True):
-        x, y, z, radius = map(_f32, (x, y, z, radius))
-        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
-        so = np.ascontiguousarray(structure_offsets, dtype=np.uint32)
+                             residue_offsets=None, want_atoms: bool = True, atom_out=None,
+                             res_out=None):
+        """Host buffers in, host buffers out.  `atom_out` / `res_out` may be preallocated float32
+        arrays (pinned host memory makes both copy directions asynchronous)."""
+        so = _offsets("structure_offsets", structure_offsets)
         n_struct = so.shape[0] - 1
-        atom_out = np.zeros(x.shape[0], np.float32) if want_atoms else None
-        ro = res_out = None
+        x, y, z, radius, ids = _columns(x, y, z, radius, ids, int(so[-1]) if n_struct else 0)
+        atom_out = _out_buffer("atom_out", atom_out, x.shape[0]) if want_atoms else None
+        ro = None
         n_res = 0
         if residue_offsets is not None:
-            ro = np.ascontiguousarray(residue_offsets, dtype=np.uint32)
+            ro = _offsets("residue_offsets", residue_offsets)
             n_res = ro.shape[0] - 1
-            res_out = np.zeros(n_res, np.float32)
+            res_out = _out_buffer("res_out", res_out, n_res)
+        else:
+            res_out = None
         self._check(self._lib.rsasa_calculate_sasa_batch(
             self._h, ptr(x), ptr(y), ptr(z), ptr(radius), ptr(ids), ptr(so), n_struct,
             probe_radius, n_points, ptr(atom_out), ptr(ro), n_res, ptr(res_out)))
@@ -116,9 +150,14 @@ class Context:
         """xyz: [n_frames, n_atoms, 3] float32 (frame-major); returns ([F, N] atom values or None,
         [F, R] residue sums or None)."""
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        if xyz.ndim != 3 or xyz.shape[2] != 3:
+            raise ValueError("xyz must have shape [n_frames, n_atoms, 3]")
         n_frames, n_atoms = xyz.shape[0], xyz.shape[1]
         radius = _f32(radius)
         ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint64)
+        for name, a in (("radius", radius), ("ids", ids)):
+            if a is not None and (a.ndim != 1 or a.shape[0] != n_atoms):
+                raise ValueError(f"{name} must be a 1-D array of {n_atoms} entries")
         atom_out = np.zeros((n_frames, n_atoms), np.float32) if want_atoms else None
         ro = res_out = None
         n_res = 0
@@ -157,11 +196,18 @@ class Context:
         b.out_atom_sasa = dp(out_atom_sasa)
         b.out_residue_sasa = dp(out_residue_sasa)
         b.out_neighbor_counts = dp(out_neighbor_counts)
-        # the library may re-run the batch from wait(): keep every buffer alive until then
-        self._keepalive = (so, x, y, z, radius, ids, residue_offsets, out_atom_sasa,
-                           out_residue_sasa, out_neighbor_counts)
-        self._check(self._lib.rsasa_batch_enqueue(self._h, C.byref(b), probe_radius, n_points,
-                                                  C.c_void_p(stream) if stream else None))
+        # The library may re-run a batch from wait(), and rsasa_batch_enqueue first waits for the
+        # batch enqueued before: the previous batch's buffers stay alive until the call returns,
+        # this batch's until its wait().
+        previous = self._keepalive
+        keep = (so, x, y, z, radius, ids, residue_offsets, out_atom_sasa, out_residue_sasa,
+                out_neighbor_counts)
+        try:
+            self._check(self._lib.rsasa_batch_enqueue(self._h, C.byref(b), probe_radius, n_points,
+                                                      C.c_void_p(stream) if stream else None))
+        finally:
+            del previous
+        self._keepalive = keep
 
     def wait(self):
         self._check(self._lib.rsasa_batch_wait(self._h))

@@ -11,3 +11,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
+
+
+def ensure_built():
+    """The engine library and the host-API test driver are build products (never tracked): build
+    them when a fresh checkout has none.  Returns the driver's path."""
+    import subprocess
+    lib = os.path.join(ROOT, "rustsasa_amd", "lib", "librustsasa_amd.so")
+    cli = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
+    if not (os.path.exists(lib) and os.path.exists(cli)):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "rustsasa_amd", "csrc"), "all"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return cli

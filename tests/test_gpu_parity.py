@@ -307,6 +307,44 @@ def test_full_proteome_properties(ctx):
         assert np.array_equal(atom[lo:hi], want)
 
 
+def test_full_proteome_every_atom_and_residue(ctx):
+    """BASELINE config 3 at FULL size against the oracle: all 4 363 structures, 11.72 M atoms and
+    1.51 M residues, bit for bit (the tolerance of north_star is 1e-4 A^2; we demand equality)."""
+    b = bw.synthetic_proteome()
+    assert b.n_structures == 4363 and b.n_atoms > 11_000_000
+    atom, res, k = _device_run(ctx, b)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                   8, threads=0)
+    bad = np.flatnonzero(atom != want)
+    assert bad.size == 0, (bad.size, bad[:5], atom[bad[:5]], want[bad[:5]])
+    assert float(np.max(np.abs(atom - want))) <= TOL
+    assert np.array_equal(res, po.residue_sums(want, b.residue_offsets))
+    assert 40.0 < k.mean() < 50.0   # SURVEY 8: 43-49 candidates per atom on protein-like input
+
+
+def test_uniform_1m_atoms_960_points_full_size(ctx):
+    """BASELINE config 5 at FULL size: one structure of 1 000 000 atoms, 960 points, AtomLevel.
+    65 536 atoms or more: the batch-wide (tail) binning route, which the 60 000-atom case above
+    does not take."""
+    b = bw.synthetic_uniform(1_000_000, seed=5)
+    atom, _, k = _device_run(ctx, b, n_points=960, want_res=False)
+    want, _, want_k = po.calculate_sasa_internal(b.x, b.y, b.z, b.radius, b.ids, PROBE, 960, 8,
+                                                 return_details=True, threads=0)
+    bad = np.flatnonzero(atom != want)
+    assert bad.size == 0, (bad.size, bad[:5], atom[bad[:5]], want[bad[:5]])
+    assert np.array_equal(k, want_k)
+
+
+@pytest.mark.parametrize("n_points", [1000, 1100])
+def test_uniform_box_many_points_with_remainder(ctx, n_points):
+    """More than 128 points with a remainder (1100 = 137 * 8 + 4) on a structure large enough for
+    the tail binning route."""
+    b = bw.synthetic_uniform(70_000, seed=9)
+    atom, _, _ = _device_run(ctx, b, n_points=n_points, want_k=False, want_res=False)
+    want = po.calculate_sasa_internal(b.x, b.y, b.z, b.radius, b.ids, PROBE, n_points, 8, threads=0)
+    assert np.array_equal(atom, want)
+
+
 @pytest.mark.parametrize("env", [{"RSASA_OCCLUSION_KERNEL": "0"},
                                  {"RSASA_OCCLUSION_KERNEL": "2", "RSASA_ATOMS_PER_WAVE": "5"},
                                  {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "1"},
@@ -407,6 +445,55 @@ def test_trajectory_mode(ctx):
     only_res = ctx.calculate_sasa_trajectory(frames, r, None, PROBE, 100, residue_offsets=ro,
                                              want_atoms=False)
     assert only_res[0] is None and np.array_equal(only_res[1], rsum)
+
+
+def test_trajectory_residues_that_do_not_cover_all_atoms(ctx):
+    """Residue offsets that start after atom 0 and end before the last atom: every frame's last
+    residue must stop at its own end, not run on into the next frame."""
+    xyz, r, res, ids = bw.fixture_soa("1jcd.pdb")
+    rng = np.random.default_rng(18)
+    frames = np.stack([(xyz + rng.normal(scale=0.3, size=xyz.shape)) for _ in range(5)]).astype(np.float32)
+    ro = res.astype(np.uint32)[2:-3]          # skips the first two and the last three residues
+    assert ro[0] > 0 and ro[-1] < len(r)
+    atom, rsum = ctx.calculate_sasa_trajectory(frames, r, ids, PROBE, 100, residue_offsets=ro)
+    assert rsum.shape == (5, len(ro) - 1)
+    for f in range(5):
+        want = po.calculate_sasa_internal(frames[f, :, 0], frames[f, :, 1], frames[f, :, 2], r, ids,
+                                          PROBE, 100, 8)
+        assert np.array_equal(atom[f], want)
+        assert np.array_equal(rsum[f], po.residue_sums(want, ro))
+    # the batch entry point with the same kind of offsets
+    x, y, z = (np.ascontiguousarray(frames[0, :, k]) for k in range(3))
+    _, rs = ctx.calculate_sasa_batch(x, y, z, r, ids, np.array([0, len(r)], np.uint32), PROBE, 100,
+                                     residue_offsets=ro)
+    assert np.array_equal(rs, rsum[0])
+
+
+def test_python_wrapper_rejects_mismatched_columns(ctx, example_vdw):
+    x, y, z, r, ids = example_vdw
+    so = np.array([0, len(x)], np.uint32)
+    with pytest.raises(ValueError):
+        ctx.calculate_sasa_batch(x, y[:-1], z, r, ids, so)
+    with pytest.raises(ValueError):
+        ctx.calculate_sasa_batch(x, y, z, r, ids[:10], so)
+    with pytest.raises(ValueError):
+        ctx.calculate_sasa_batch(x, y, z, r, ids, np.array([0, len(x) + 5], np.uint32))
+    with pytest.raises(ValueError):
+        ctx.calculate_sasa_soa(x, y, z, r[:5], ids)
+    with pytest.raises(ValueError):
+        ctx.calculate_sasa_batch(x, y, z, r, ids, so, res_out=np.zeros(3, np.float32),
+                                 residue_offsets=np.array([0, 5, len(x)], np.uint32))
+    got = ctx.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100)
+    assert np.max(np.abs(got - sio.load_golden_low_res())) <= TOL
+
+
+def test_calls_leave_the_current_device_alone(ctx, example_vdw):
+    """Entry points run on the context's device and restore the caller's current device."""
+    import torch
+    x, y, z, r, ids = example_vdw
+    before = torch.cuda.current_device()
+    ctx.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100)
+    assert torch.cuda.current_device() == before
 
 
 def test_fast_kernel_defers_dense_atoms_inside_a_mixed_batch(ctx):
@@ -515,6 +602,23 @@ def test_host_batch_pipelined_sub_batches(ctx):
         lo, hi = int(b.structure_offsets[s]), int(b.structure_offsets[s + 1])
         want = po.calculate_sasa_internal(*b.structure(int(s)), PROBE, 100, 8)
         assert np.array_equal(atom[lo:hi], want)
+    # pinned (page-locked) host arrays in and out: every copy is asynchronous, the results leave on
+    # their own stream while the next sub-batch computes
+    import torch
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()  # noqa: E731
+    pa, pr = pin(np.full(b.n_atoms, -1.0, np.float32)), pin(np.full(b.n_residues, -1.0, np.float32))
+    for _ in range(2):
+        a3, r3 = ctx.calculate_sasa_batch(pin(b.x), pin(b.y), pin(b.z), pin(b.radius), pin(b.ids),
+                                          b.structure_offsets, PROBE, 100, residue_offsets=pin(b.residue_offsets),
+                                          atom_out=pa, res_out=pr)
+        assert a3 is pa and r3 is pr
+        assert np.array_equal(pa, atom_dev) and np.array_equal(pr, res_dev)
+        pa[:] = -1.0
+        pr[:] = -1.0
+    # pinned residues only, pageable inputs
+    _, r4 = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                     residue_offsets=b.residue_offsets, want_atoms=False, res_out=pr)
+    assert np.array_equal(r4, res_dev)
 
 
 def test_small_host_batches_take_the_short_path_and_agree(monkeypatch):

@@ -12,7 +12,9 @@ import structio as sio
 from oracle import pyoracle as po
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLI = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
+from conftest import ensure_built
+
+CLI = ensure_built()
 FIXTURES = ["example.cif", "1jcd.pdb", "151L_H3.pdb", "bad_seqadv_1A06.pdb", "2drt.pdb"]
 POLAR = {"SER", "THR", "CYS", "ASN", "GLN", "TYR"}
 

@@ -9,6 +9,6 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def test_reader_survives_mutated_files():
     import fuzz_reader
-    cli = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
-    assert os.path.exists(cli)
+    from conftest import ensure_built
+    cli = ensure_built()
     assert fuzz_reader.run_cases(cli, 60, seed=11) == []

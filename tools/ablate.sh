@@ -1,10 +1,13 @@
 #!/bin/bash
 # Timing ablation of k_occlusion_v3: RSASA_DEBUG_STOP=n skips the stages after point n
 # (results are wrong in those runs; only the kernel time and instruction counts are read).
+# The switch exists only in the ablation library: build it first with
+#   make -C rustsasa_amd/csrc ablate            (-> rustsasa_amd/lib/variants/ablate/)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+LIB=$PWD/rustsasa_amd/lib/variants/ablate/librustsasa_amd.so
+RUN="import sys; sys.path.insert(0, '.'); import rustsasa_amd._capi as c; c.LIB_PATH = '$LIB'; import bench; bench.main()"
 for s in 1 6 2 3 4 5 0; do
-  export RSASA_DEBUG_STOP=$s
-  ms=$(python3 bench.py --steps 5 --warmup 1 --cpu-seconds 0 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms']['occlusion'])")
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/abl_$s -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 > /dev/null 2>&1
-  echo "stop=$s occlusion_ms=$ms $(python3 tools/pmc_summary.py "gpurun_out/abl_$s/**/*counter_collection.csv" | grep -E 'INSTS' | awk '{printf "%s=%s ", $1, $NF}')"
+  export RSASA_DEBUG_STOP=$s RSASA_OCCLUSION_KERNEL=3
+  ms=$(python3 -c "$RUN" --steps 5 --warmup 1 --cpu-seconds 0 --h2h-steps 0 2>/dev/null | tail -1 | python3 -c "import sys,json; print(json.loads(sys.stdin.read())['kernel_ms']['occlusion'])")
+  echo "stop=$s occlusion_ms=$ms"
 done

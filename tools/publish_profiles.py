@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Copies gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/round1_final_* and derives
-profiles/pmc_occlusion.json (HBM bytes per occlusion launch, read by bench.py)."""
+"""Copies gpurun_out/<tag>/ (tools/profile_round.sh) into profiles/<prefix>_* and derives
+profiles/pmc_occlusion.json (HBM bytes and VALU instructions per occlusion launch, read by bench.py).
+usage: tools/publish_profiles.py <tag> [prefix, default round2_final]"""
 import json
 import os
 import re
@@ -9,12 +10,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else "round2_final"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
-names = {"bench.json": "round1_final_bench.json", "bench_under_rocprof.json": "round1_final_bench_under_rocprof.json",
-         "kernel_stats.csv": "round1_final_kernel_stats.csv", "pmc.txt": "round1_final_pmc.txt",
-         "bench_uniform1m.json": "round1_final_bench_uniform1m.json", "single_and_pcie.json": "round1_single_and_pcie.json",
-         "files_mode.json": "round1_files_mode.json"}
+names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
+                                        "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json")}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 10:
@@ -26,14 +26,17 @@ def val(name):
     return int(re.search(name + r"\s+(\d+)", txt).group(1))
 
 
+kernel = re.search(r"dispatch \d+: (.*?)\( grid", txt).group(1).strip()
+
+
 fetch_kb, write_kb = val("FETCH_SIZE"), val("WRITE_SIZE")
 hit, miss = val("TCC_HIT_sum"), val("TCC_MISS_sum")
 bench = json.load(open(os.path.join(src, "bench.json")))
 out = {
-    "kernel": "k_occlusion_fast<true, true> (+ k_occlusion_v3 in list mode over the deferred atoms: none in this workload)",
+    "kernel": kernel + " (+ k_occlusion_v3 in list mode over the deferred atoms: none in this workload)",
     "workload": "bench.py default (synthetic proteome, 4363 structures, 11.72 M atoms, 100 points)",
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum, separate passes "
-              "(tools/profile_round.sh, profiles/round1_final_pmc.txt)",
+              "(tools/profile_round.sh, profiles/" + prefix + "_pmc.txt)",
     "FETCH_SIZE_KB": fetch_kb,
     "WRITE_SIZE_KB": write_kb,
     "correction": "gfx950: FETCH_SIZE reports half of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM); the "
@@ -41,6 +44,8 @@ out = {
     "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
     "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
     "tcc_hit_rate": round(hit / (hit + miss), 4),
+    "valu_insts_per_launch": val("SQ_INSTS_VALU"),
+    "salu_insts_per_launch": val("SQ_INSTS_SALU"),
 }
 json.dump(out, open(os.path.join(dst, "pmc_occlusion.json"), "w"), indent=2)
 print(json.dumps(out, indent=1))
