@@ -83,7 +83,7 @@ struct rsasa_context {
 
     // workspace (device)
     DeviceBuffer segments, acc, grids, grid_sums, sid, sid_sorted, deferred_list, cell_of, rank_of, cells, scan_sums, sorted_xyzr,
-        sorted_orig, sorted_id, status, atom_sasa;
+        sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
     DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res;  // second input slot of the pipelined host-buffer path
@@ -293,6 +293,7 @@ int enqueue_pending(rsasa_context *ctx)
     if ((rc = reserve(ctx, ctx->sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
     if (has_id && (rc = reserve(ctx, ctx->sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
+    if (has_id && (rc = reserve(ctx, ctx->sorted_id32, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->status, sizeof(BatchStatus)))) return rc;
     if (!bt.out_atom_sasa && (rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
 
@@ -321,6 +322,7 @@ int enqueue_pending(rsasa_context *ctx)
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
     v.sorted_id = has_id ? (uint64_t *)ctx->sorted_id.p : nullptr;
+    v.sorted_id32 = has_id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
     v.status = (BatchStatus *)ctx->status.p;
     v.atom_sasa = bt.out_atom_sasa ? bt.out_atom_sasa : (float *)ctx->atom_sasa.p;
     v.residue_sasa = (R && bt.residue_offsets) ? bt.out_residue_sasa : nullptr;
@@ -506,7 +508,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
-                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->status, &ctx->atom_sasa,
+                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
                             &ctx->atom_sasa2, &ctx->out_res2,
@@ -743,6 +745,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if ((rc = reserve(ctx, ctx->sorted_xyzr, N * 16))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_orig, N * 4))) return rc;
     if (id && (rc = reserve(ctx, ctx->sorted_id, N * 8))) return rc;
+    if (id && (rc = reserve(ctx, ctx->sorted_id32, N * 4))) return rc;
 
     char *h = (char *)ctx->h_small;
     BatchStatus stt{};
@@ -779,6 +782,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
     v.sorted_id = id ? (uint64_t *)ctx->sorted_id.p : nullptr;
+    v.sorted_id32 = id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
     v.atom_sasa = (float *)(dout + o_oa);
     v.residue_sasa = R ? (float *)(dout + o_or) : nullptr;
     launch_sort_lds_single(v, st);

@@ -89,6 +89,7 @@ struct BatchView {
     float4 *sorted_xyzr;          // cell-sorted (x, y, z, radius)
     uint32_t *sorted_orig;        // cell-sorted position -> input index
     uint64_t *sorted_id;          // cell-sorted ids (only when id != null)
+    uint32_t *sorted_id32;        // the same folded to 32 bits (fold_id): different folds => different ids
     BatchStatus *status;
     // outputs
     float *atom_sasa;             // never null (workspace buffer when the caller passed none)
@@ -99,8 +100,9 @@ struct BatchView {
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
-    int kernel_version = 4;       // 0 = all-pairs reference kernel, 3 = general culled-sweep kernel for every atom,
-                                  // 4 = straight-line fast kernel + the general kernel for the atoms it defers
+    int kernel_version = 5;       // 0 = all-pairs reference kernel, 3 = general culled-sweep kernel for every atom,
+                                  // 4 = straight-line per-atom kernel, 5 = group-union sweep + matrix-core point
+                                  // tests (4 and 5 leave the atoms they cannot take to the general kernel)
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
     uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
 };

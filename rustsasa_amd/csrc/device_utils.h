@@ -92,6 +92,10 @@ __device__ __forceinline__ void cell_coords(const StructGrid &g, float x, float 
 }
 
 
+// 64-bit atom id -> 32 bits.  Only used as a filter: ids whose folds differ are different; equal
+// folds are decided on the full ids (the general kernel).
+__device__ __forceinline__ uint32_t fold_id(uint64_t id) { return (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B1u); }
+
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 }  // namespace

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(1024) void k_sort_small(BatchView b)
                     b.sorted_xyzr[pos] = v[k];
                     b.sorted_orig[pos] = i;
                     b.sid_sorted[pos] = s;
-                    if (pid) b.sorted_id[pos] = id[k];
+                    if (pid) { b.sorted_id[pos] = id[k]; b.sorted_id32[pos] = fold_id(id[k]); }
                 }
             }
         }
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
     b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
     b.sorted_orig[pos] = i;
     b.sid_sorted[pos] = s;
-    if (b.id) b.sorted_id[pos] = b.id[i];
+    if (b.id) { const uint64_t v = b.id[i]; b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
 }
 
 // ResidueLevel value: strictly sequential f32 sum of the residue's atoms in

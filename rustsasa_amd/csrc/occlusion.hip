@@ -59,6 +59,7 @@ __device__ __forceinline__ uint32_t mbcnt64(unsigned long long m)
 
 #include "occlusion_v3.inc"
 #include "occlusion_fast.inc"
+#include "occlusion_mx.inc"
 
 template <int NCH>
 void launch_v0(const OccArgs &a, hipStream_t stream)
@@ -72,6 +73,15 @@ void launch_fast2(bool half1, uint32_t n_blocks, hipStream_t stream, const OccAr
 {
     if (half1) hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, true>), dim3(n_blocks), dim3(256), 0, stream, a3);
     else hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+}
+
+template <int NT>
+void launch_mx(bool has_id, bool rem, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
+{
+    if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true>), dim3(n_blocks), dim3(256), 0, stream, a3);
+    else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+    else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true>), dim3(n_blocks), dim3(256), 0, stream, a3);
+    else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
 }
 
 void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
@@ -121,7 +131,14 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         const bool rem = lat.n_points != lat.n_fused;
         const bool half1 = lat.n_fused <= 96u;  // the second chunk's fused points fit half a wave
         a3.part = part;
-        launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
+        if (tune.kernel_version >= 5) {
+            // group-union sweep + matrix-core point tests: 64 atoms per wave
+            const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * kMxAtoms);
+            if (lat.n_fused <= 96u) launch_mx<6>(b.id != nullptr, rem, mx_blocks, stream, a3);
+            else launch_mx<8>(b.id != nullptr, rem, mx_blocks, stream, a3);
+        } else {
+            launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
+        }
         if (part == kOccHead) return;  // the general kernel follows the last fast launch
         a3.work_list = b.deferred_list;
         a3.work_count = &b.status->deferred;
