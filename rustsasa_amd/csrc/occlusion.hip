@@ -75,13 +75,13 @@ void launch_fast2(bool half1, uint32_t n_blocks, hipStream_t stream, const OccAr
     else hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
 }
 
-template <int NT>
-void launch_mx(bool has_id, bool rem, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
+template <int NT, bool MULTI>
+void launch_mx(bool has_id, bool rem, uint32_t n_blocks, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
 {
-    if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true>), dim3(n_blocks), dim3(256), 0, stream, a3);
-    else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
-    else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true>), dim3(n_blocks), dim3(256), 0, stream, a3);
-    else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+    if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
+    else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
+    else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
+    else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
 }
 
 void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
@@ -100,7 +100,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     if (!b.n_atoms) return;
     OccArgs a{b, lat, 0, 1, tune.debug_stop};
     const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
-    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && n_chunks <= 2 &&
+    // the straight-line kernels: few remainder points; up to 128 points (k_occlusion_fast), or up to
+    // kMxMaxPoints with the matrix-core kernel
+    const bool mx = tune.kernel_version >= 5 && lat.n_fused <= kMxMaxPoints;
+    const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && (n_chunks <= 2 || mx) &&
                       lat.n_points - lat.n_fused <= kFastMaxRem;
     if (!fast && part == kOccHead) return;  // only the fast kernel takes a partial range
     if (tune.kernel_version == 0) {
@@ -131,11 +134,12 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         const bool rem = lat.n_points != lat.n_fused;
         const bool half1 = lat.n_fused <= 96u;  // the second chunk's fused points fit half a wave
         a3.part = part;
-        if (tune.kernel_version >= 5) {
+        if (mx) {
             // group-union sweep + matrix-core point tests: 64 atoms per wave
             const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * kMxAtoms);
-            if (lat.n_fused <= 96u) launch_mx<6>(b.id != nullptr, rem, mx_blocks, stream, a3);
-            else launch_mx<8>(b.id != nullptr, rem, mx_blocks, stream, a3);
+            if (lat.n_fused <= 96u) launch_mx<6, false>(b.id != nullptr, rem, mx_blocks, 4u * 96u * 4u, stream, a3);
+            else if (lat.n_fused <= 128u) launch_mx<8, false>(b.id != nullptr, rem, mx_blocks, 4u * 128u * 4u, stream, a3);
+            else launch_mx<6, true>(b.id != nullptr, rem, mx_blocks, 4u * 96u * cdiv(lat.n_fused, 96u) * 4u, stream, a3);
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }
