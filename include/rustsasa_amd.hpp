@@ -11,9 +11,18 @@
 //
 // The reference parses files with the `pdbtbx` crate, whose source is not
 // available here; `Structure` is this library's own minimal PDB / mmCIF
-// atom-record model.  Differences that can matter are documented in DESIGN.md
-// ("Host API"): first MODEL only; a residue's first conformer is the first
-// (residue name, alt-loc) pair met in file order.
+// atom-record model.  Where its behaviour cannot be pinned against pdbtbx
+// (DESIGN.md "Host API") this library makes its own, documented choice:
+//   * multi-model files (NMR ensembles): ONLY THE FIRST MODEL is read.  The
+//     reference iterates pdb.chains() / pdb.residues(), which in pdbtbx appear
+//     to span every model; if they do, the reference sums an ensemble's models
+//     into one result where this library reports model 1.  Single-model files
+//     (every fixture of the reference's tests, every AlphaFold model) are
+//     unaffected;
+//   * a residue's first conformer (`conformers().next()`, src/options.rs:162,255)
+//     is the first (residue name, alt-loc) pair met in file order: checked
+//     against the reference's own quality gate on alt-loc files
+//     (tests/test_host_api.py, fixtures tests/golden/data/freesasa/).
 #pragma once
 
 #include <cstdint>

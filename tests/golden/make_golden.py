@@ -23,6 +23,10 @@ DATA_FILES = [
     "tests/data/freesasa_pdbs/2drt.pdb",   # small clean multi-chain file with HETATM
     "radii/protor.config",                 # ProtOr radii table (FreeSASA data file)
 ]
+# Small files WITH alternate locations from the reference's quality set (tests/quality.rs runs the
+# whole tests/data/freesasa_pdbs directory, 46 MB; these are its six smallest alt-loc files), each
+# with its FreeSASA chain totals (tests/data/freesasa_reference/<id>.json).
+ALTLOC_IDS = ["2gpi", "3w7y", "3uc7", "3kyz", "4oxx", "3zsj"]
 
 
 def main():
@@ -31,6 +35,13 @@ def main():
         dst = os.path.join(HERE, "data", os.path.basename(rel))
         shutil.copyfile(os.path.join(REF, rel), dst)
         os.chmod(dst, 0o644)
+
+    os.makedirs(os.path.join(HERE, "data", "freesasa"), exist_ok=True)
+    for pid in ALTLOC_IDS:
+        for rel in (f"tests/data/freesasa_pdbs/{pid}.pdb", f"tests/data/freesasa_reference/{pid}.json"):
+            dst = os.path.join(HERE, "data", "freesasa", os.path.basename(rel))
+            shutil.copyfile(os.path.join(REF, rel), dst)
+            os.chmod(dst, 0o644)
 
     text = open(os.path.join(REF, "tests/common/data.rs")).read()
     m = re.search(r"FIXED_LOW_RES_ATOMS:\s*\[f32;\s*(\d+)\]\s*=\s*\[(.*?)\];", text, re.S)

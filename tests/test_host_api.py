@@ -318,3 +318,62 @@ def test_json_shape_matches_serde():
     assert list(first.keys()) == ["serial_number", "insertion_code", "value", "name", "is_polar", "chain_id"]
     prot = subprocess.run([CLI, "protein", sio.data_path("2drt.pdb")], capture_output=True, text=True).stdout
     assert list(json.loads(prot)["Protein"].keys()) == ["global_total", "polar_total", "non_polar_total"]
+
+
+# ---- files with alternate locations (the reference's quality set, tests/quality.rs) -----------
+ALTLOC = ["2gpi", "3w7y", "3uc7", "3kyz", "4oxx", "3zsj"]
+RMSE_GATE = 43.99 + 20.0   # RMSE_BASELINE + TOLERANCE, reference tests/quality.rs:17-18,225
+
+
+def _altloc_count(name):
+    return sum(1 for a in sio.read_structure(sio.data_path(name)) if a.altloc not in ("", " "))
+
+
+@pytest.mark.parametrize("pid", ALTLOC)
+def test_altloc_reader_counts_match_independent_parser(pid):
+    name = f"freesasa/{pid}.pdb"
+    assert _altloc_count(name) > 0          # the fixture really exercises alternate locations
+    atoms = sio.read_structure(sio.data_path(name))
+    got = run_cli("parse", name)
+    assert got["atoms"] == len(atoms)
+    assert got["chains"] == len({a.chain for a in atoms})
+    assert got["residues"] == len({(a.chain, a.resseq, a.icode) for a in atoms})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pid", ALTLOC)
+def test_first_conformer_selection_on_altloc_files(pid):
+    """A residue contributes its FIRST conformer only (reference src/options.rs:162,255:
+    `residue.conformers().next()`): here the first (residue name, alt-loc) pair met in file order.
+    The C++ reader must select exactly the atoms the independent Python reader selects, give them
+    the same radii, and do so deterministically."""
+    name = f"freesasa/{pid}.pdb"
+    atom, res, meta = expected(name)
+    n_all = sum(1 for a in sio.read_structure(sio.data_path(name)) if not a.hetero and a.element != "H")
+    assert len(atom) < n_all                # alternate conformers were dropped
+    first = run_cli("atom", name)["Atom"]
+    again = run_cli("atom", name)["Atom"]
+    assert first == again
+    assert len(first) == len(atom)
+    assert np.array_equal(np.array(first, np.float32), atom)
+    got_res = run_cli("residue", name)["Residue"]
+    assert [g["serial_number"] for g in got_res] == [m[0] for m in meta]
+    assert np.array_equal(np.array([g["value"] for g in got_res], np.float32), res)
+
+
+@pytest.mark.gpu
+def test_altloc_files_meet_the_reference_quality_gate():
+    """The reference's own gate on this kind of input (tests/quality.rs:225): RMSE of the chain
+    totals against FreeSASA's (Lee & Richards, a different algorithm) at most 63.99 A^2."""
+    ours, theirs = [], []
+    for pid in ALTLOC:
+        ref = json.load(open(sio.data_path(f"freesasa/{pid}.json")))
+        want = {c["label"]: c["area"]["total"] for r in ref["results"] for s in r["structure"] for c in s["chains"]}
+        got = {c["name"]: c["value"] for c in run_cli("chain", f"freesasa/{pid}.pdb")["Chain"]}
+        common = sorted(set(want) & set(got))
+        assert common, (pid, want.keys(), got.keys())
+        ours += [got[k] for k in common]
+        theirs += [want[k] for k in common]
+    rmse = float(np.sqrt(np.mean((np.array(ours) - np.array(theirs)) ** 2)))
+    assert len(ours) >= len(ALTLOC)
+    assert rmse <= RMSE_GATE, rmse
