@@ -843,15 +843,20 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     const size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
     std::vector<size_t> cut{0};        // structure indices where sub-batches begin / end
     if (N >= 2 * kSubAtoms && n_structures > 1) {
-        const size_t n_sub = std::min<size_t>(8, N / kSubAtoms);
+        size_t max_sub = 8;
+        if (const char *v = std::getenv("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
+        const size_t n_sub = std::min<size_t>(max_sub, N / kSubAtoms);
+        // The first sub-batch's upload is not hidden behind anything: it gets half a share.
+        const size_t first = N / (2 * n_sub - 1), share = (N - first) / (n_sub - 1);
+        auto boundary = [&](size_t k) { return first + (k - 1) * share; };  // first atom of sub-batch k >= 1
         size_t next = 1;
         for (size_t sidx = 1; sidx < n_structures && next < n_sub; sidx++) {
             const size_t a0 = structure_offsets[sidx];
-            if (a0 < next * (N / n_sub)) continue;
+            if (a0 < boundary(next)) continue;
             if (want_res && !std::binary_search(residue_offsets, residue_offsets + n_residues + 1, (uint32_t)a0))
                 continue;  // a residue spans this structure boundary: cut later
             cut.push_back(sidx);
-            next = a0 / (N / n_sub) + 1;
+            while (next < n_sub && boundary(next) <= a0) next++;
         }
     }
     cut.push_back(n_structures);

@@ -100,9 +100,10 @@ struct BatchView {
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
-    int kernel_version = 5;       // 0 = all-pairs reference kernel, 3 = general culled-sweep kernel for every atom,
+    int kernel_version = 6;       // 0 = all-pairs reference kernel, 3 = general culled-sweep kernel for every atom,
                                   // 4 = straight-line per-atom kernel, 5 = group-union sweep + matrix-core point
-                                  // tests (4 and 5 leave the atoms they cannot take to the general kernel)
+                                  // tests (4 and 5 leave the atoms they cannot take to the general kernel),
+                                  // 6 = 5 for batches of 65 536 atoms or more, 4 below
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
     uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
 };

@@ -102,7 +102,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
     // the straight-line kernels: few remainder points; up to 128 points (k_occlusion_fast), or up to
     // kMxMaxPoints with the matrix-core kernel
-    const bool mx = tune.kernel_version >= 5 && lat.n_fused <= kMxMaxPoints;
+    // (6 = default: the matrix-core kernel once the batch has enough atoms to fill the GPU with its
+    // 64-atom waves; smaller batches - single structures - finish sooner on the per-atom kernels)
+    const bool mx = tune.kernel_version >= 5 && lat.n_fused <= kMxMaxPoints &&
+                    (tune.kernel_version == 5 || b.n_atoms >= kMxMinAtoms);
     const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && (n_chunks <= 2 || mx) &&
                       lat.n_points - lat.n_fused <= kFastMaxRem;
     if (!fast && part == kOccHead) return;  // only the fast kernel takes a partial range
@@ -136,7 +139,13 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         a3.part = part;
         if (mx) {
             // group-union sweep + matrix-core point tests: 64 atoms per wave
-            const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * kMxAtoms);
+            // 64 atoms per wave once the batch fills the GPU (256 CUs x 4 SIMDs x ~6 waves), fewer
+            // (down to 8) for small batches, where the time of one wave is the time of the call
+            uint32_t apw = kMxAtoms;
+            if (tune.atoms_per_wave > 0) apw = min(tune.atoms_per_wave, kMxAtoms);
+            else while (apw > 8u && (uint64_t)apw * (256u * 4u * 6u) > b.n_atoms) apw >>= 1;
+            a3.atoms_per_wave = apw;
+            const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * apw);
             if (lat.n_fused <= 96u) launch_mx<6, false>(b.id != nullptr, rem, mx_blocks, 4u * 96u * 4u, stream, a3);
             else if (lat.n_fused <= 128u) launch_mx<8, false>(b.id != nullptr, rem, mx_blocks, 4u * 128u * 4u, stream, a3);
             else launch_mx<6, true>(b.id != nullptr, rem, mx_blocks, 4u * 96u * cdiv(lat.n_fused, 96u) * 4u, stream, a3);

@@ -351,6 +351,9 @@ def test_uniform_box_many_points_with_remainder(ctx, n_points):
                                  {"RSASA_OCCLUSION_KERNEL": "3", "RSASA_ATOMS_PER_WAVE": "7"},
                                  {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "1"},
                                  {"RSASA_OCCLUSION_KERNEL": "4", "RSASA_ATOMS_PER_WAVE": "3"},
+                                 {"RSASA_OCCLUSION_KERNEL": "5"},
+                                 {"RSASA_OCCLUSION_KERNEL": "5", "RSASA_ATOMS_PER_WAVE": "8"},
+                                 {"RSASA_OCCLUSION_KERNEL": "5", "RSASA_ATOMS_PER_WAVE": "23"},
                                  {"RSASA_OVERLAP_TAIL": "1"},
                                  {"RSASA_SMALL_PATH": "0"}])
 def test_kernel_variants_agree(env, monkeypatch):
@@ -373,6 +376,46 @@ def test_kernel_variants_agree(env, monkeypatch):
 
 
 # ---- size-independent properties ----------------------------------------------------
+
+def test_small_inputs_on_the_matrix_core_kernel(monkeypatch):
+    """By default batches below 65 536 atoms take the per-atom kernels (lower latency per call), so
+    the small cases of this file would never reach k_occlusion_mx: force it (RSASA_OCCLUSION_KERNEL=5)
+    through point counts with and without remainder points, every lane count of the remainder rule,
+    duplicate ids, coincident atoms, empty and tiny structures."""
+    import rustsasa_amd
+    monkeypatch.setenv("RSASA_OCCLUSION_KERNEL", "5")
+    rng = np.random.default_rng(12)
+    with rustsasa_amd.Context(0) as c:
+        for name in ("1jcd.pdb", "example.cif"):
+            xyz, r, _, ids = bw.fixture_soa(name)
+            x, y, z = (np.ascontiguousarray(xyz[:, k]).astype(np.float32) for k in range(3))
+            for n_points in (1, 17, 96, 100, 128, 129, 200, 960, 1000, 1100, 2020):
+                got = c.calculate_sasa_soa(x, y, z, r, ids, PROBE, n_points)
+                assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, 8)), (name, n_points)
+            # ids: none, and duplicated (atoms sharing an id never occlude each other)
+            got = c.calculate_sasa_soa(x, y, z, r, None, PROBE, 100)
+            assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, None, PROBE, 100, 8))
+            dup = ids.copy()
+            dup[rng.choice(len(dup), 200, replace=False)] = dup[0]
+            got = c.calculate_sasa_soa(x, y, z, r, dup, PROBE, 100)
+            assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, dup, PROBE, 100, 8))
+        # coincident atoms, an isolated atom, tiny and empty structures in one batch
+        x = np.array([0, 0, 0, 50, 1.0, 1.5, 2.0, 9.0], np.float32)
+        y = np.zeros(8, np.float32)
+        z = np.zeros(8, np.float32)
+        r = np.array([1.5, 1.5, 1.7, 1.5, 1.2, 1.8, 1.5, 1.5], np.float32)
+        so = np.array([0, 4, 4, 5, 8], np.uint32)
+        got, _ = c.calculate_sasa_batch(x, y, z, r, None, so, PROBE, 100)
+        want = po.calculate_sasa_batch(x, y, z, r, None, so, PROBE, 100, 8, threads=1)
+        assert np.array_equal(got, want)
+    for w in (1, 4, 16):
+        xyz, r, _, ids = bw.fixture_soa("151L_H3.pdb")
+        x, y, z = (np.ascontiguousarray(xyz[:, k]).astype(np.float32) for k in range(3))
+        with rustsasa_amd.Context(0, simd_width=w) as c:
+            for n_points in (100, 103, 960):
+                got = c.calculate_sasa_soa(x, y, z, r, ids, PROBE, n_points)
+                assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, w)), (w, n_points)
+
 
 def test_permutation_invariance(ctx):
     """A per-atom value depends on the SET of atoms, not on their order in the input: shuffling
