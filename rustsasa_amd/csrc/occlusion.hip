@@ -146,9 +146,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             else while (apw > 8u && (uint64_t)apw * (256u * 4u * 6u) > b.n_atoms) apw >>= 1;
             a3.atoms_per_wave = apw;
             const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * apw);
-            if (lat.n_fused <= 96u) launch_mx<6, false>(b.id != nullptr, rem, mx_blocks, 4u * 96u * 4u, stream, a3);
-            else if (lat.n_fused <= 128u) launch_mx<8, false>(b.id != nullptr, rem, mx_blocks, 4u * 128u * 4u, stream, a3);
-            else launch_mx<6, true>(b.id != nullptr, rem, mx_blocks, 4u * 96u * cdiv(lat.n_fused, 96u) * 4u, stream, a3);
+            // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
+            if (lat.n_fused <= 96u) launch_mx<6, false>(b.id != nullptr, rem, mx_blocks, 24u * 96u, stream, a3);
+            else if (lat.n_fused <= 128u) launch_mx<8, false>(b.id != nullptr, rem, mx_blocks, 24u * 128u, stream, a3);
+            else launch_mx<6, true>(b.id != nullptr, rem, mx_blocks, 24u * 96u * cdiv(lat.n_fused, 96u), stream, a3);
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }

@@ -116,6 +116,31 @@ __global__ __launch_bounds__(256) void k_time(int iters, float *out)
 #define MIN4(mm, dd) asm volatile("v_min3_f32 %0, %0, %1, %2\n v_min3_f32 %0, %0, %3, %4" : "+v"(mm) : "v"(dd[0]), "v"(dd[1]), "v"(dd[2]), "v"(dd[3]));
             MIN4(m[0], d0) MIN4(m[1], d1) MIN4(m[2], d2) MIN4(m[3], d3) MIN4(m[4], d4) MIN4(m[5], d5)
         }
+        if (MODE == 8 || MODE == 9 || MODE == 10) {
+            // f16 matrix instructions (16x16x16, f32 accumulate) next to vector work: do the pipes overlap?
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 ha = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)e};
+            h4 hb = {(_Float16)pt[0], (_Float16)pt[1], (_Float16)pt[2], (_Float16)pt[3]};
+            if (MODE != 10) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, hb, acc[i], 0, 0, 0);
+            }
+            if (MODE != 8) {
+                REP4(REP4(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %0\n v_fma_f32 %2, %2, %0, %1\n v_fma_f32 %3, %3, %2, %1\n v_fma_f32 %0, %0, %3, %2\n v_fma_f32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));))
+            }
+        }
+        if (MODE == 11 || MODE == 12) {
+            // the same with independent (non-accumulating) f16 matrix instructions
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 ha = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)e};
+            h4 hb = {(_Float16)pt[0], (_Float16)pt[1], (_Float16)pt[2], (_Float16)pt[3]};
+            f4 zz = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 6; i++) { f4 d = __builtin_amdgcn_mfma_f32_16x16x16f16(ha, hb, zz, 0, 0, 0); m[i] = fmaxf(m[i], d[0] + d[3]); }
+            if (MODE == 12) {
+                REP4(REP4(asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %0\n v_fma_f32 %2, %2, %0, %1\n v_fma_f32 %3, %3, %2, %1\n v_fma_f32 %0, %0, %3, %2\n v_fma_f32 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));))
+            }
+        }
         if (MODE == 4) {  // the vector version of one phase-A trip pair: 8 candidates x 128 points = 54 VALU
             for (int q = 0; q < 2; q++) {
                 REP4(asm volatile("v_mul_f32 %3, %0, %1\n v_fma_f32 %3, %1, %2, %3\n v_fma_f32 %3, %2, %0, %3\n v_sub_f32 %3, %1, %3\n v_mul_f32 %0, %3, %1\n v_fma_f32 %0, %1, %2, %0\n" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));)
@@ -212,6 +237,11 @@ int main()
         run<6>("asm: 6 MFMA -> 12 v_min3 at once", d, w);
         run<5>("asm: 6 MFMA, 24 v_fma filler, 12 v_min3", d, w);
         run<7>("asm: 6 MFMA, 96 v_fma filler, 12 v_min3", d, w);
+        run<8>("6 f16 MFMA 16x16x16 (chained accumulators)", d, w);
+        run<10>("96 v_fma_f32", d, w);
+        run<9>("6 f16 MFMA 16x16x16 + 96 v_fma_f32", d, w);
+        run<11>("6 independent f16 MFMA + 6 x 2 VALU", d, w);
+        run<12>("6 independent f16 MFMA + 6 x 2 VALU + 96 v_fma_f32", d, w);
     }
     printf(rc ? "MFMA_CHECK_FAILED\n" : "MFMA_CHECK_OK\n");
     return rc;
