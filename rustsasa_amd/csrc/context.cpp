@@ -86,22 +86,32 @@ struct rsasa_context {
         sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
-    DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res;  // second input slot of the pipelined host-buffer path
-    DeviceBuffer atom_sasa2, out_res2;            // second output slot of the same path
+    // further input / output slots of the pipelined host-buffer path (kSlots sub-batches in flight)
+    DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res, in3_x, in3_y, in3_z, in3_r, in3_id, in3_res;
+    DeviceBuffer atom_sasa2, out_res2, atom_sasa3, out_res3;
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
     hipStream_t d2h_stream = nullptr;             // D2H of the previous sub-batch's results meanwhile
-    hipEvent_t ev_copy[2] = {nullptr, nullptr};
-    hipEvent_t ev_d2h[2] = {nullptr, nullptr};    // output slot k has been copied out
-    void *h_out[2] = {nullptr, nullptr};          // pinned staging for results whose destination is pageable
-    size_t h_out_cap[2] = {0, 0};
+    static constexpr int kSlots = 3;
+    hipEvent_t ev_copy[kSlots] = {};
+    hipEvent_t ev_d2h[kSlots] = {};               // output slot k has been copied out
+    void *h_out[kSlots] = {};                     // pinned staging for results whose destination is pageable
+    size_t h_out_cap[kSlots] = {};
     DeviceBuffer small_in, small_out;          // small host batches: one upload / one download buffer
     void *h_small = nullptr;                   // pinned staging of the same layout
     size_t h_small_cap = 0;
     DeviceBuffer tr_xyz, tr_r, tr_id, tr_res;  // trajectory staging (frame-major xyz, per-topology columns)
     // pinned host
-    Segment *h_segments = nullptr;
-    size_t h_segments_cap = 0;
-    BatchStatus *h_status = nullptr;
+    // Host side of one enqueued batch (pinned): its bounds segments (source of an async upload) and
+    // the status block the device writes back.  Slot 0 serves the batch entry points; the pipelined
+    // host-buffer path keeps two sub-batches in flight and alternates between slots 0 and 1.
+    struct HostSlot {
+        Segment *h_segments = nullptr;
+        size_t h_segments_cap = 0;
+        BatchStatus *h_status = nullptr;
+        uint32_t *h_res = nullptr;      // rebased residue offsets of a sub-batch (a pageable source would
+        size_t h_res_cap = 0;           // make the "asynchronous" upload wait for the copy stream)
+    } slot[kSlots];
+    hipEvent_t ev_done[kSlots] = {};              // all work of the sub-batch in slot k has been executed
     uint64_t cell_capacity = 0;
 
     std::map<std::pair<size_t, int>, LatticeEntry> lattices;
@@ -235,10 +245,9 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
     return RSASA_OK;
 }
 
-// Enqueues the whole pipeline for ctx->pending on its stream.
-int enqueue_pending(rsasa_context *ctx)
+// Enqueues the whole pipeline for the batch `pd` on its stream, using host slot `hs`.
+int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot &hs)
 {
-    Pending &pd = ctx->pending;
     const rsasa_device_batch_t &bt = pd.batch;
     const size_t N = bt.n_atoms, S = bt.n_structures, R = bt.n_residues;
     hipStream_t st = pd.stream;
@@ -253,23 +262,23 @@ int enqueue_pending(rsasa_context *ctx)
         const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
         n_seg += (e - b + kSegmentAtoms - 1) / kSegmentAtoms;
     }
-    if (n_seg > ctx->h_segments_cap) {
-        if (ctx->h_segments) {
+    if (n_seg > hs.h_segments_cap) {
+        if (hs.h_segments) {
             RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            RS_HIP(ctx, hipHostFree(ctx->h_segments));
-            ctx->h_segments = nullptr;
-            ctx->h_segments_cap = 0;
+            RS_HIP(ctx, hipHostFree(hs.h_segments));
+            hs.h_segments = nullptr;
+            hs.h_segments_cap = 0;
         }
         const size_t cap = n_seg + n_seg / 2 + 64;
-        RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_segments, cap * sizeof(Segment), hipHostMallocDefault));
-        ctx->h_segments_cap = cap;
+        RS_HIP(ctx, hipHostMalloc((void **)&hs.h_segments, cap * sizeof(Segment), hipHostMallocDefault));
+        hs.h_segments_cap = cap;
     }
     {
         size_t k = 0;
         for (size_t s = 0; s < S; s++) {
             const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
             for (uint32_t a = b; a < e; a += kSegmentAtoms)
-                ctx->h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms)};
+                hs.h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms)};
         }
     }
 
@@ -298,7 +307,7 @@ int enqueue_pending(rsasa_context *ctx)
     if (!bt.out_atom_sasa && (rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
 
     if (n_seg)
-        RS_HIP(ctx, hipMemcpyAsync(ctx->segments.p, ctx->h_segments, n_seg * sizeof(Segment),
+        RS_HIP(ctx, hipMemcpyAsync(ctx->segments.p, hs.h_segments, n_seg * sizeof(Segment),
                                    hipMemcpyHostToDevice, st));
 
     BatchView v{};
@@ -355,7 +364,7 @@ int enqueue_pending(rsasa_context *ctx)
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
     launch_residue_sums(v, st);
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
-    RS_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->status.p, sizeof(BatchStatus),
+    RS_HIP(ctx, hipMemcpyAsync(hs.h_status, ctx->status.p, sizeof(BatchStatus),
                                hipMemcpyDeviceToHost, st));
     RS_HIP(ctx, hipGetLastError());
     return RSASA_OK;
@@ -371,7 +380,7 @@ int wait_pending(rsasa_context *ctx)
             pd.active = false;
             return fail(ctx, RSASA_ERR_HIP, "hipStreamSynchronize", e);
         }
-        const BatchStatus stt = *ctx->h_status;
+        const BatchStatus stt = *ctx->slot[0].h_status;
         if (stt.grid_too_large) {
             pd.active = false;
             return fail(ctx, RSASA_ERR_GRID_TOO_LARGE,
@@ -402,7 +411,7 @@ int wait_pending(rsasa_context *ctx)
         }
         ctx->cell_capacity = stt.total_cells + stt.total_cells / 8 + 1024;
         pd.attempts++;
-        int rc = enqueue_pending(ctx);
+        int rc = enqueue_batch(ctx, pd, ctx->slot[0]);
         if (rc) {
             pd.active = false;
             return rc;
@@ -480,15 +489,17 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming);
-    if (e == hipSuccess)
-        e = hipHostMalloc((void **)&ctx->h_status, sizeof(BatchStatus), hipHostMallocDefault);
+    for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
+    for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming);
+    for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) {
+        e = hipHostMalloc((void **)&ctx->slot[i].h_status, sizeof(BatchStatus), hipHostMallocDefault);
+        if (e == hipSuccess) std::memset(ctx->slot[i].h_status, 0, sizeof(BatchStatus));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_done[i], hipEventDisableTiming);
+    }
     if (e != hipSuccess) {
         rsasa_context_destroy(ctx);
         return RSASA_ERR_HIP;
     }
-    std::memset(ctx->h_status, 0, sizeof(BatchStatus));
     if (const char *v = std::getenv("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
     if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
 #ifdef RSASA_ABLATE  // timing-ablation builds only (make ablate): the shipped library has no wrong-results switch
@@ -511,19 +522,24 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
-                            &ctx->atom_sasa2, &ctx->out_res2,
+                            &ctx->in3_x, &ctx->in3_y, &ctx->in3_z, &ctx->in3_r, &ctx->in3_id, &ctx->in3_res,
+                            &ctx->atom_sasa2, &ctx->out_res2, &ctx->atom_sasa3, &ctx->out_res3,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
                             &ctx->tr_id, &ctx->tr_res})
         release(*b);
     for (auto &kv : ctx->lattices)
         if (kv.second.d) (void)hipFree(kv.second.d);
-    if (ctx->h_segments) (void)hipHostFree(ctx->h_segments);
-    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    for (int i = 0; i < rsasa_context::kSlots; i++) {
+        if (ctx->slot[i].h_segments) (void)hipHostFree(ctx->slot[i].h_segments);
+        if (ctx->slot[i].h_status) (void)hipHostFree(ctx->slot[i].h_status);
+        if (ctx->slot[i].h_res) (void)hipHostFree(ctx->slot[i].h_res);
+        if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
+    }
     for (int i = 0; i < 4; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < rsasa_context::kSlots; i++)
         if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < rsasa_context::kSlots; i++) {
         if (ctx->ev_d2h[i]) (void)hipEventDestroy(ctx->ev_d2h[i]);
         if (ctx->h_out[i]) (void)hipHostFree(ctx->h_out[i]);
     }
@@ -624,7 +640,7 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
     ctx->pending.n_points = n_points;
     ctx->pending.stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     ctx->pending.attempts = 0;
-    rc = enqueue_pending(ctx);
+    rc = enqueue_batch(ctx, ctx->pending, ctx->slot[0]);
     ctx->pending.active = (rc == RSASA_OK);
     return rc;
 }
@@ -874,11 +890,14 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
     const bool piped = cut.size() > 2;
     const size_t n_sub = cut.size() - 1;
-    DeviceBuffer *bx[2] = {&ctx->in_x, &ctx->in2_x}, *by[2] = {&ctx->in_y, &ctx->in2_y};
-    DeviceBuffer *bz[2] = {&ctx->in_z, &ctx->in2_z}, *br[2] = {&ctx->in_r, &ctx->in2_r};
-    DeviceBuffer *bi[2] = {&ctx->in_id, &ctx->in2_id}, *bo[2] = {&ctx->in_res, &ctx->in2_res};
-    DeviceBuffer *oa[2] = {&ctx->atom_sasa, &ctx->atom_sasa2}, *orr[2] = {&ctx->out_res, &ctx->out_res2};
-    for (int k = 0; k < (piped ? 2 : 1); k++) {
+    constexpr int kSlots = rsasa_context::kSlots;
+    const int n_slots = piped ? kSlots : 1;
+    DeviceBuffer *bx[kSlots] = {&ctx->in_x, &ctx->in2_x, &ctx->in3_x}, *by[kSlots] = {&ctx->in_y, &ctx->in2_y, &ctx->in3_y};
+    DeviceBuffer *bz[kSlots] = {&ctx->in_z, &ctx->in2_z, &ctx->in3_z}, *br[kSlots] = {&ctx->in_r, &ctx->in2_r, &ctx->in3_r};
+    DeviceBuffer *bi[kSlots] = {&ctx->in_id, &ctx->in2_id, &ctx->in3_id}, *bo[kSlots] = {&ctx->in_res, &ctx->in2_res, &ctx->in3_res};
+    DeviceBuffer *oa[kSlots] = {&ctx->atom_sasa, &ctx->atom_sasa2, &ctx->atom_sasa3};
+    DeviceBuffer *orr[kSlots] = {&ctx->out_res, &ctx->out_res2, &ctx->out_res3};
+    for (int k = 0; k < n_slots; k++) {
         if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
@@ -904,7 +923,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     const bool res_direct = !want_res || is_pinned(out_residue_sasa);
     const size_t stage_atoms = (out_atom_sasa && !atoms_direct) ? max_atoms * 4 : 0;
     const size_t stage_bytes = stage_atoms + ((want_res && !res_direct) ? max_res * 4 : 0);
-    for (int k = 0; k < (piped ? 2 : 1) && stage_bytes; k++) {
+    for (int k = 0; k < n_slots && stage_bytes; k++) {
         if (stage_bytes <= ctx->h_out_cap[k]) continue;
         if (ctx->h_out[k]) {
             RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
@@ -917,9 +936,23 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
 
     // host copies of the rebased offsets stay alive until their sub-batch has been waited for
-    std::vector<uint32_t> so[2], ro[2];
+    std::vector<uint32_t> so[kSlots];
+    for (int k = 0; k < n_slots && want_res; k++) {
+        rsasa_context::HostSlot &hs = ctx->slot[k];
+        if (max_res + 1 <= hs.h_res_cap) continue;
+        if (hs.h_res) {
+            RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+            RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            RS_HIP(ctx, hipHostFree(hs.h_res));
+            hs.h_res = nullptr;
+            hs.h_res_cap = 0;
+        }
+        const size_t cap = max_res + 1 + max_res / 4;
+        RS_HIP(ctx, hipHostMalloc((void **)&hs.h_res, cap * sizeof(uint32_t), hipHostMallocDefault));
+        hs.h_res_cap = cap;
+    }
     auto upload = [&](size_t c, hipStream_t st) -> int {
-        const int k = (int)(c & 1);
+        const int k = (int)(c % kSlots);
         const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
         so[k].resize(s1 - s0 + 1);
         for (size_t i = s0; i <= s1; i++) so[k][i - s0] = structure_offsets[i] - (uint32_t)a0;
@@ -932,14 +965,14 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         }
         if (want_res) {
             const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
-            ro[k].resize(r1 - r0 + 1);
-            for (size_t i = r0; i <= r1; i++) ro[k][i - r0] = residue_offsets[i] - (uint32_t)a0;
-            RS_HIP(ctx, hipMemcpyAsync(bo[k]->p, ro[k].data(), (r1 - r0 + 1) * 4, hipMemcpyHostToDevice, st));
+            uint32_t *ro = ctx->slot[k].h_res;
+            for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
+            RS_HIP(ctx, hipMemcpyAsync(bo[k]->p, ro, (r1 - r0 + 1) * 4, hipMemcpyHostToDevice, st));
         }
         return RSASA_OK;
     };
     auto enqueue = [&](size_t c) -> int {
-        const int k = (int)(c & 1);
+        const int k = (int)(c % kSlots);
         const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
         const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
         rsasa_device_batch_t bt{};
@@ -960,7 +993,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         return rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr);
     };
     // staged results of output slot k that still have to be moved to the caller's arrays
-    struct Staged { bool active = false; size_t a0 = 0, na = 0, r0 = 0, nr = 0; } staged[2];
+    struct Staged { bool active = false; size_t a0 = 0, na = 0, r0 = 0, nr = 0; } staged[kSlots];
     auto drain = [&](int k) -> int {
         if (!staged[k].active) return RSASA_OK;
         RS_HIP(ctx, hipEventSynchronize(ctx->ev_d2h[k]));
@@ -973,35 +1006,11 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         return RSASA_OK;
     };
 
-    // Three streams: copy-in (sub-batch c + 1), compute (c), copy-out (c - 1).  The host waits for
-    // sub-batch c (its status decides whether it has to run again with a larger cell array),
-    // queues the kernels of c + 1 right away and only then starts c's copy-out.
-    hipStream_t st = ctx->stream, cp = piped ? ctx->copy_stream : ctx->stream, dn = ctx->d2h_stream;
-    if ((rc = upload(0, cp))) return rc;
-    if (piped) {
-        RS_HIP(ctx, hipEventRecord(ctx->ev_copy[0], cp));
-        RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[0], 0));
-    }
-    if ((rc = enqueue(0))) return rc;
-    bool d2h_used[2] = {false, false};
-    for (size_t c = 0; c < n_sub; c++) {
-        const int k = (int)(c & 1);
+    hipStream_t st = ctx->stream, dn = ctx->d2h_stream;
+    auto copy_out = [&](size_t c) -> int {  // sub-batch c's results (all its kernels have been waited for or ordered before)
+        const int k = (int)(c % kSlots);
         const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
         const size_t r0 = res_cut[c], nr = want_res ? res_cut[c + 1] - r0 : 0;
-        // feed the next sub-batch: input slot k ^ 1 was last read by sub-batch c - 1 (waited for).
-        // (A copy from pageable memory keeps this thread busy, so it comes after c's enqueue.)
-        if (c + 1 < n_sub) {
-            if ((rc = upload(c + 1, cp))) return rc;
-            RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k ^ 1], cp));
-        }
-        if ((na || nr) && (rc = rsasa_batch_wait(ctx))) return rc;
-        if (c + 1 < n_sub) {
-            RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k ^ 1], 0));
-            // output slot k ^ 1 must have left the device (sub-batch c - 1's copy-out)
-            if (d2h_used[k ^ 1]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k ^ 1], 0));
-            if ((rc = enqueue(c + 1))) return rc;
-        }
-        if ((rc = drain(k))) return rc;  // staging slot k still holds sub-batch c - 2
         char *h = (char *)ctx->h_out[k];
         if (out_atom_sasa && na)
             RS_HIP(ctx, hipMemcpyAsync(atoms_direct ? (void *)(out_atom_sasa + a0) : (void *)h, oa[k]->p, na * 4,
@@ -1010,14 +1019,101 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             RS_HIP(ctx, hipMemcpyAsync(res_direct ? (void *)(out_residue_sasa + r0) : (void *)(h + stage_atoms),
                                        orr[k]->p, nr * 4, hipMemcpyDeviceToHost, dn));
         RS_HIP(ctx, hipEventRecord(ctx->ev_d2h[k], dn));
-        d2h_used[k] = true;
         staged[k].active = stage_bytes != 0;
         staged[k].a0 = a0; staged[k].na = na; staged[k].r0 = r0; staged[k].nr = nr;
+        return RSASA_OK;
+    };
+    if (!piped) {
+        // one sub-batch: upload, kernels, wait (re-runs with a larger cell array if needed), copy out
+        if ((rc = upload(0, st))) return rc;
+        if ((rc = enqueue(0))) return rc;
+        const size_t na = structure_offsets[cut[1]], nr = want_res ? res_cut[1] : 0;
+        if ((na || nr) && (rc = rsasa_batch_wait(ctx))) return rc;
+        if ((rc = copy_out(0))) return rc;
+        if ((rc = drain(0))) return rc;
+        RS_HIP(ctx, hipStreamSynchronize(dn));
+        return RSASA_OK;
     }
-    if ((rc = drain(0))) return rc;
-    if ((rc = drain(1))) return rc;
-    RS_HIP(ctx, hipStreamSynchronize(dn));
-    return RSASA_OK;
+
+    // Several sub-batches on three streams: copy-in (sub-batch c + 1), compute (c), copy-out (c - 1).
+    // kSlots sub-batches are in flight: the host queues the next one (upload, then kernels behind the
+    // upload's event) while earlier ones compute and never waits in between - the uploads, which are the
+    // longest leg (PCIe), follow each other without a gap.  A
+    // sub-batch's status block (host slot c % kSlots) is only read when its slot is needed again or at
+    // the end; if one of them reports that the cell array was too small, everything is drained, the
+    // array grows to the largest size reported and the call starts over (outputs are simply
+    // written again) - that happens on a context's first large call at most.
+    if (n_points == 0 || n_points > (1u << 24))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "n_points must be in [1, 2^24]");
+    if (!(probe_radius >= 0.0f) || !std::isfinite(probe_radius))
+        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius must be finite and >= 0");
+    for (size_t sidx = 0; sidx < n_structures; sidx++)
+        if (structure_offsets[sidx] > structure_offsets[sidx + 1])
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must be non-decreasing");
+    if (structure_offsets[0] != 0) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must span [0, n_atoms]");
+    hipStream_t cp = ctx->copy_stream;
+    for (int attempt = 0;; attempt++) {
+        uint64_t need_cells = 0;
+        int err = RSASA_OK;
+        auto check = [&](int k) {  // status of the sub-batch that used host slot k (its event has been waited for)
+            const BatchStatus stt = *ctx->slot[k].h_status;
+            if (stt.grid_too_large && !err)
+                err = fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "a structure's cell grid exceeds 2^31 cells (coordinates too sparse)");
+            if (stt.bad_input && !err)
+                err = fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius + max radius must be a positive finite number");
+            if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
+        };
+        bool used[kSlots] = {};
+        for (size_t c = 0; c < n_sub; c++) {
+            const int k = (int)(c % kSlots);
+            if (used[k]) {
+                // slot k (host segments / status, input and output buffers) was sub-batch c - kSlots's
+                RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
+                check(k);
+                if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
+            }
+            if ((rc = upload(c, cp))) return rc;
+            RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
+            RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
+            if (used[k]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k], 0));  // output slot k has left the device
+            const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
+            const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
+            Pending pd;
+            pd.batch.x = (const float *)bx[k]->p;
+            pd.batch.y = (const float *)by[k]->p;
+            pd.batch.z = (const float *)bz[k]->p;
+            pd.batch.radius = (const float *)br[k]->p;
+            pd.batch.id = id ? (const uint64_t *)bi[k]->p : nullptr;
+            pd.batch.structure_offsets_host = so[k].data();
+            pd.batch.n_structures = s1 - s0;
+            pd.batch.n_atoms = na;
+            pd.batch.residue_offsets = nr ? (const uint32_t *)bo[k]->p : nullptr;
+            pd.batch.n_residues = nr;
+            pd.batch.out_atom_sasa = (float *)oa[k]->p;
+            pd.batch.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
+            pd.batch.out_neighbor_counts = nullptr;
+            pd.probe = probe_radius;
+            pd.n_points = n_points;
+            pd.stream = st;
+            if ((rc = enqueue_batch(ctx, pd, ctx->slot[k]))) return rc;
+            RS_HIP(ctx, hipEventRecord(ctx->ev_done[k], st));
+            RS_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_done[k], 0));
+            if ((rc = copy_out(c))) return rc;
+            used[k] = true;
+        }
+        for (int k = 0; k < kSlots; k++) {
+            if (!used[k]) continue;
+            RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
+            check(k);
+            if ((rc = drain(k))) return rc;
+        }
+        RS_HIP(ctx, hipStreamSynchronize(dn));
+        if (err) return err;
+        if (!need_cells) return RSASA_OK;
+        if (need_cells >= 0xFFFFFFF0ull || attempt >= 3)
+            return fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "batch needs more than 2^32 grid cells; split it");
+        ctx->cell_capacity = need_cells + need_cells / 8 + 1024;
+    }
 }
 
 int rsasa_calculate_sasa_soa(rsasa_context_t *ctx, const float *x, const float *y,
