@@ -341,16 +341,25 @@ def main():
                                           "peak_insts_per_s": VALU_PEAK_INSTS,
                                           "frac": round(rate / VALU_PEAK_INSTS, 4), "source": PMC_FILE}
         else:
-            # config 5 is bound by the vector ALUs: n_points * K point tests per atom,
-            # 3 FMA + 1 compare each; no HBM fraction is claimed
-            flops = 7.0 * n_points * k_sum
-            achieved = flops / (occl * 1e-3) / 1e12
-            roofline = {"bound": "valu", "kernel": "k_occlusion", "achieved": round(achieved, 3),
+            # config 5 is bound by the vector ALUs: no HBM fraction is claimed.  Utilisation =
+            # vector instructions the occlusion launch executed (rocprofv3 SQ_INSTS_VALU, profiles/) x 64
+            # lanes x 2 flop, as if every one were a full-wave FMA, against the f32 vector peak.
+            pmcu = {}
+            try:
+                pmcu = json.load(open(os.path.join(ROOT, "profiles", "pmc_uniform1m.json")))
+            except Exception:
+                pmcu = {}
+            vi = pmcu.get("valu_insts_per_launch") if (world == 1 and batch.n_atoms == 1_000_000 and n_points == 960) else None
+            achieved = vi * 128.0 / (occl * 1e-3) / 1e12 if vi else None
+            roofline = {"bound": "valu", "kernel": "k_occlusion",
+                        "achieved": round(achieved, 3) if achieved else None,
                         "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / VALU_PEAK_TFLOPS, 4),
-                        "frac_of": "upper-bound point tests (n_points * sum K, 3 FMA + 1 compare = 7 flop "
-                                   "each) / kernel time / f32 vector peak; the kernel skips tests the "
-                                   "upper bound counts, so this is work-equivalent throughput",
+                        "frac": round(achieved / VALU_PEAK_TFLOPS, 4) if achieved else None,
+                        "frac_of": "vector-ALU utilisation: executed vector instructions (profiles/pmc_uniform1m.json) "
+                                   "x 64 lanes x 2 flop / kernel time / f32 vector peak; matrix instructions count "
+                                   "as one instruction each although they hold the pipe for 8-32 cycles",
+                        "valu_insts_per_launch": vi, "mfma_insts_per_launch": pmcu.get("mfma_insts_per_launch") if vi else None,
+                        "point_tests_upper_bound_per_launch": int(n_points) * int(k_sum),
                         "traffic": None, "kernel_ms": round(occl, 4)}
         line = {
             "metric": "structures/sec on AF2 E. coli proteome (100 pts, 1.4 A probe)",

@@ -21,6 +21,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $one > /dev/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $one > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_tcc -- $one > /dev/null 2>&1
 python3 tools/pmc_summary.py "$out/pmc_*/**/*counter_collection.csv" > $out/pmc.txt 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH --output-format csv -d $out/pmcu_a -- python3 bench.py --workload uniform1m --steps 1 --warmup 0 --cpu-seconds 0 --h2h-steps 0 > /dev/null 2>&1
+python3 tools/pmc_summary.py "$out/pmcu_*/**/*counter_collection.csv" > $out/pmc_uniform1m.txt 2>&1
+rm -rf $out/pmcu_a
 python3 bench.py --workload uniform1m --cpu-seconds 0 --h2h-steps 0 > $out/u1m.log 2>&1; tail -1 $out/u1m.log > $out/bench_uniform1m.json
 python3 tools/bench_single.py 2>/dev/null > $out/single_and_pcie.json
 python3 tools/bench_files.py --files 1500 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json

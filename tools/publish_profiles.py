@@ -14,7 +14,7 @@ prefix = sys.argv[2] if len(sys.argv) > 2 else "round2_final"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
-                                        "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json")}
+                                        "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json", "pmc_uniform1m.txt")}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 10:
@@ -26,7 +26,7 @@ def val(name):
     return int(re.search(name + r"\s+(\d+)", txt).group(1))
 
 
-kernel = re.search(r"dispatch \d+: (.*?)\( grid", txt).group(1).strip()
+kernel = re.search(r"dispatch \d+: (.*?) grid=", txt).group(1).strip()
 
 
 fetch_kb, write_kb = val("FETCH_SIZE"), val("WRITE_SIZE")
@@ -49,3 +49,16 @@ out = {
 }
 json.dump(out, open(os.path.join(dst, "pmc_occlusion.json"), "w"), indent=2)
 print(json.dumps(out, indent=1))
+
+# the same for the 1M-atom / 960-point workload (config 5): instruction counts of its occlusion launch
+pu = os.path.join(src, "pmc_uniform1m.txt")
+if os.path.exists(pu):
+    tu = open(pu).read()
+    vu = lambda name: int(re.search(name + r"\s+(\d+)", tu).group(1))  # noqa: E731
+    outu = {"kernel": re.search(r"dispatch \d+: (.*?) grid=", tu).group(1).strip(),
+            "workload": "bench.py --workload uniform1m (1 000 000 atoms in one structure, 960 points)",
+            "source": "rocprofv3 --pmc SQ_INSTS_* (tools/profile_round.sh, profiles/" + prefix + "_pmc_uniform1m.txt)",
+            "valu_insts_per_launch": vu("SQ_INSTS_VALU"), "mfma_insts_per_launch": vu("SQ_INSTS_MFMA"),
+            "salu_insts_per_launch": vu("SQ_INSTS_SALU"), "lds_insts_per_launch": vu("SQ_INSTS_LDS")}
+    json.dump(outu, open(os.path.join(dst, "pmc_uniform1m.json"), "w"), indent=2)
+    print(json.dumps(outu, indent=1))
