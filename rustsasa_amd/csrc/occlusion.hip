@@ -139,11 +139,12 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         a3.part = part;
         if (mx) {
             // group-union sweep + matrix-core point tests: 64 atoms per wave
-            // 64 atoms per wave once the batch fills the GPU (256 CUs x 4 SIMDs x ~6 waves), fewer
-            // (down to 8) for small batches, where the time of one wave is the time of the call
+            // 64 atoms per wave once that still leaves about four rounds of waves (256 CUs x 4 SIMDs x 7
+            // waves resident) - fewer (down to 8) for smaller batches, where the last, partly filled round
+            // and, for single structures, the time of one wave set the time of the call
             uint32_t apw = kMxAtoms;
             if (tune.atoms_per_wave > 0) apw = min(tune.atoms_per_wave, kMxAtoms);
-            else while (apw > 8u && (uint64_t)apw * (256u * 4u * 6u) > b.n_atoms) apw >>= 1;
+            else while (apw > 8u && (uint64_t)apw * (256u * 4u * 7u * 4u) > b.n_atoms) apw >>= 1;
             a3.atoms_per_wave = apw;
             const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * apw);
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
