@@ -359,18 +359,25 @@ __global__ __launch_bounds__(256) void k_zero_cells(BatchView b)
 
 // Count atoms per cell (spatial_grid.rs:53-62); the atomic's return value is
 // the atom's slot inside its cell, so the scatter needs no second atomic.
+constexpr uint32_t kSegmentParts = 4;  // workgroups per bounds segment in the tail's histogram / scatter
+
+// kSegmentParts workgroups per bounds segment (<= kSegmentAtoms atoms of ONE structure): the segments of
+// LDS-binned structures - nearly all of them in a batch of proteins - return at once instead of
+// reading every atom's structure and grid.
 __global__ __launch_bounds__(256) void k_cell_hist(BatchView b)
 {
     if (batch_aborted(b.status)) return;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n_atoms) return;
-    const StructGrid g = b.grids[b.sid[i]];
+    const Segment seg = b.segments[blockIdx.x / kSegmentParts];
+    const StructGrid g = b.grids[seg.sid];
     if (g.in_lds) return;
-    uint32_t cx, cy, cz;
-    cell_coords(g, b.x[i], b.y[i], b.z[i], cx, cy, cz);
-    uint32_t cell = g.cell_base + cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
-    b.cell_of[i] = cell;
-    b.rank_of[i] = atomicAdd(&b.cells[cell], 1u);
+    const uint32_t part = kSegmentAtoms / kSegmentParts, p0 = seg.begin + (blockIdx.x % kSegmentParts) * part;
+    for (uint32_t i = p0 + threadIdx.x; i < min(seg.end, p0 + part); i += blockDim.x) {
+        uint32_t cx, cy, cz;
+        cell_coords(g, b.x[i], b.y[i], b.z[i], cx, cy, cz);
+        const uint32_t cell = g.cell_base + cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
+        b.cell_of[i] = cell;
+        b.rank_of[i] = atomicAdd(&b.cells[cell], 1u);
+    }
 }
 
 // Exclusive prefix sum of the cell counts (spatial_grid.rs:65-68), three
@@ -443,15 +450,17 @@ __global__ __launch_bounds__(256) void k_scan_apply(BatchView b)
 __global__ __launch_bounds__(256) void k_scatter(BatchView b)
 {
     if (batch_aborted(b.status)) return;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b.n_atoms) return;
-    const uint32_t s = b.sid[i];
+    const Segment seg = b.segments[blockIdx.x / kSegmentParts];
+    const uint32_t s = seg.sid;
     if (b.grids[s].in_lds) return;
-    uint32_t pos = b.cells[b.cell_of[i]] + b.rank_of[i];
-    b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
-    b.sorted_orig[pos] = i;
-    b.sid_sorted[pos] = s;
-    if (b.id) { const uint64_t v = b.id[i]; b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
+    const uint32_t part = kSegmentAtoms / kSegmentParts, p0 = seg.begin + (blockIdx.x % kSegmentParts) * part;
+    for (uint32_t i = p0 + threadIdx.x; i < min(seg.end, p0 + part); i += blockDim.x) {
+        const uint32_t pos = b.cells[b.cell_of[i]] + b.rank_of[i];
+        b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
+        b.sorted_orig[pos] = i;
+        b.sid_sorted[pos] = s;
+        if (b.id) { const uint64_t v = b.id[i]; b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
+    }
 }
 
 // ResidueLevel value: strictly sequential f32 sum of the residue's atoms in
@@ -503,13 +512,13 @@ void launch_sort_lds_single(const BatchView &b, hipStream_t stream)
 void launch_sort_tail(const BatchView &b, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_zero_cells, dim3(2048), dim3(256), 0, stream, b);
-    if (b.n_atoms)
-        hipLaunchKernelGGL(k_cell_hist, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);
+    if (b.n_segments)
+        hipLaunchKernelGGL(k_cell_hist, dim3(b.n_segments * kSegmentParts), dim3(256), 0, stream, b);
     hipLaunchKernelGGL(k_scan_reduce, dim3(kScanBlocks), dim3(256), 0, stream, b);
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(kScanBlocks), 0, stream, b);
     hipLaunchKernelGGL(k_scan_apply, dim3(kScanBlocks), dim3(256), 0, stream, b);
-    if (b.n_atoms)
-        hipLaunchKernelGGL(k_scatter, dim3(cdiv(b.n_atoms, 256)), dim3(256), 0, stream, b);
+    if (b.n_segments)
+        hipLaunchKernelGGL(k_scatter, dim3(b.n_segments * kSegmentParts), dim3(256), 0, stream, b);
 }
 
 // Trajectory frames: xyz is frame-major [n_frames][n_atoms][3] (what MD readers hand over);

@@ -158,7 +158,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         a3.work_list = b.deferred_list;
         a3.work_count = &b.status->deferred;
         a3.atoms_per_wave = 1;
-        const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), 2048u);
+        const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), 1024u);  // (grid-stride over the list: usually empty)
         if (b.id) hipLaunchKernelGGL((k_occlusion_v3<2, true, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
         else hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
         return;
