@@ -82,7 +82,7 @@ struct rsasa_context {
     bool timings_valid = false;
 
     // workspace (device)
-    DeviceBuffer segments, acc, grids, grid_sums, sid, sid_sorted, deferred_list, cell_of, rank_of, cells, scan_sums, sorted_xyzr,
+    DeviceBuffer segments, acc, grids, grid_sums, sid, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums, sorted_xyzr,
         sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
@@ -273,10 +273,12 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
         RS_HIP(ctx, hipHostMalloc((void **)&hs.h_segments, cap * sizeof(Segment), hipHostMallocDefault));
         hs.h_segments_cap = cap;
     }
+    bool has_tail = false;  // some structure is too large for the LDS binning: the batch-wide kernels run too
     {
         size_t k = 0;
         for (size_t s = 0; s < S; s++) {
             const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
+            has_tail |= e - b >= kLdsMaxAtoms;
             for (uint32_t a = b; a < e; a += kSegmentAtoms)
                 hs.h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms)};
         }
@@ -298,6 +300,10 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, ctx->rank_of, std::max<size_t>(N, 1) * 4))) return rc;
     // + 1 end marker, + 3: k_zero_cells / k_scan_* access whole 16-byte vectors up to the end marker
     if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1 + 3) * 4))) return rc;
+    // one k_sort_window workgroup per window of kWindowCells 16-bit cell entries (two per entry of the cell
+    // array), at most one partly filled window per structure: whatever fits the cell array fits this list
+    const uint64_t window_capacity = std::min<uint64_t>(2 * ctx->cell_capacity / kWindowCells + S + 1, 0x7FFFFFFFull);
+    if ((rc = reserve(ctx, ctx->windows, (size_t)window_capacity * sizeof(uint2)))) return rc;
     if ((rc = reserve(ctx, ctx->scan_sums, kScanBlocks * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
@@ -327,6 +333,8 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.rank_of = (uint32_t *)ctx->rank_of.p;
     v.cells = (uint32_t *)ctx->cells.p;
     v.cell_capacity = ctx->cell_capacity;
+    v.windows = (uint2 *)ctx->windows.p;
+    v.window_capacity = (uint32_t)window_capacity;
     v.scan_block_sums = (uint32_t *)ctx->scan_sums.p;
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
@@ -342,7 +350,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     // batch-wide binning, which is bandwidth bound and runs next to the compute-bound occlusion kernel.
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     launch_grid_prepare(v, st);
-    const bool overlap = ctx->overlap_tail;
+    const bool overlap = ctx->overlap_tail && has_tail;
     if (overlap) {
         launch_sort_lds(v, st);
         // fork here, not before the LDS binning: two bandwidth-bound phases gain nothing from
@@ -357,7 +365,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
         launch_occlusion(v, lat, ctx->tuning, kOccRest, st);
     } else {
         launch_sort_lds(v, st);
-        launch_sort_tail(v, st);
+        if (has_tail) launch_sort_tail(v, st);
         if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
     }
@@ -398,7 +406,7 @@ int wait_pending(rsasa_context *ctx)
                 (void)hipEventElapsedTime(&o, ctx->ev[1], ctx->ev[2]);
                 (void)hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]);
                 (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]);
-                ctx->timings = rsasa_timings_t{g, o, a, t, stt.total_cells, pd.batch.n_atoms, stt.deferred};
+                ctx->timings = rsasa_timings_t{g, o, a, t, stt.grid_cells, pd.batch.n_atoms, stt.deferred};
                 ctx->timings_valid = true;
             }
             pd.active = false;
@@ -518,7 +526,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
-                            &ctx->rank_of, &ctx->cells, &ctx->scan_sums, &ctx->sorted_xyzr,
+                            &ctx->rank_of, &ctx->cells, &ctx->windows, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
@@ -674,7 +682,7 @@ bool small_grid(const float mn_in[3], const float mx_in[3], float max_r, float p
         if (!(e >= 0.0f) || e >= 2147483648.0f) return false;
         d[k] = (uint32_t)e + 1u;
         nc *= d[k];
-        if (nc > (unsigned long long)kMaxLdsWindows * kLdsCells) return false;
+        if (nc > 64ull * kWindowCells) return false;  // (a sparse structure: the general path)
     }
     g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
     g.inv_cell = inv;
@@ -683,7 +691,7 @@ bool small_grid(const float mn_in[3], const float mx_in[3], float max_r, float p
     g.cell_size = cell;
     g.n_cells = (uint32_t)nc;
     g.n_atoms = n_atoms;
-    g.in_lds = 2u;  // k_sort_small<2> takes every structure of a small batch
+    g.in_lds = 1u;  // fewer than kLdsMaxAtoms atoms (kSmallAtoms): binned in LDS
     *out = g;
     return true;
 }
@@ -708,7 +716,8 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     const size_t N = so[S];
     if (N == 0 || N > kSmallAtoms) return kNotSmall;
     std::vector<StructGrid> grids(S);
-    unsigned long long total_cells = 0;
+    std::vector<uint2> windows;  // work list of k_sort_window (the general path builds it on the device)
+    unsigned long long total_cells = 0;  // 16-bit entries of the cell array
     for (size_t s = 0; s < S; s++) {
         if (so[s] > so[s + 1]) return kNotSmall;  // (the general path reports it)
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mr = 0.0f;
@@ -727,16 +736,18 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
         grids[s].atom_begin = so[s];
         grids[s].sorted_base = so[s];
         grids[s].cell_base = (uint32_t)total_cells;
-        total_cells += grids[s].n_cells;
+        total_cells += lds_cell_slots(grids[s].n_cells);
+        for (uint32_t w = 0; w < grid_windows(grids[s].n_cells); w++) windows.push_back(make_uint2((uint32_t)s, w));
     }
-    const unsigned long long tail_begin = (total_cells + 1ull + 1023ull) & ~1023ull;
+    const unsigned long long tail_begin = (total_cells / 2ull + 1023ull) & ~1023ull;
+    const size_t W = windows.size();
 
     Lattice lat;
     int rc = get_lattice(ctx, n_points, &lat);
     if (rc) return rc;
-    // staging layout (16-byte aligned sections): status | grids | x | y | z | r | id | residue offsets
+    // staging layout (16-byte aligned sections): status | grids | windows | x | y | z | r | id | residue offsets
     auto up = [](size_t v) { return (v + 15) & ~size_t(15); };
-    const size_t o_grid = 64, o_x = o_grid + S * sizeof(StructGrid), o_y = o_x + up(N * 4), o_z = o_y + up(N * 4),
+    const size_t o_grid = 64, o_win = o_grid + S * sizeof(StructGrid), o_x = o_win + up(W * sizeof(uint2)), o_y = o_x + up(N * 4), o_z = o_y + up(N * 4),
                  o_r = o_z + up(N * 4), o_id = o_r + up(N * 4), o_res = o_id + (id ? up(N * 8) : 0),
                  in_bytes = o_res + (R ? up((R + 1) * 4) : 0);
     const size_t o_oa = 0, o_or = up(N * 4), out_bytes = o_or + up(R * 4);
@@ -768,8 +779,10 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     stt.total_cells = tail_begin;
     stt.tail_cell_begin = tail_begin;
     stt.tail_atom_base = (uint32_t)N;
+    stt.n_windows = (uint32_t)W;
     std::memcpy(h, &stt, sizeof stt);
     std::memcpy(h + o_grid, grids.data(), S * sizeof(StructGrid));
+    if (W) std::memcpy(h + o_win, windows.data(), W * sizeof(uint2));
     std::memcpy(h + o_x, x, N * 4);
     std::memcpy(h + o_y, y, N * 4);
     std::memcpy(h + o_z, z, N * 4);
@@ -795,13 +808,15 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     v.rank_of = (uint32_t *)ctx->rank_of.p;
     v.cells = (uint32_t *)ctx->cells.p;
     v.cell_capacity = tail_begin + 8;
+    v.windows = (uint2 *)(d + o_win);
+    v.window_capacity = (uint32_t)W;
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
     v.sorted_id = id ? (uint64_t *)ctx->sorted_id.p : nullptr;
     v.sorted_id32 = id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
     v.atom_sasa = (float *)(dout + o_oa);
     v.residue_sasa = R ? (float *)(dout + o_or) : nullptr;
-    launch_sort_lds_single(v, st);
+    launch_sort_lds(v, st);
     launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
     launch_residue_sums(v, st);
     char *hout = h + in_bytes;

@@ -11,14 +11,16 @@ struct StructGrid {
     float min_x, min_y, min_z;     // bounding-box minimum minus cell_size (spatial_grid.rs:124-127)
     float inv_cell;                // 1.0 / cell_size                      (spatial_grid.rs:36)
     uint32_t dim_x, dim_y, dim_z;  // ceil(extent * inv_cell) + 1          (spatial_grid.rs:39-43)
-    uint32_t cell_base;            // first cell of this structure in the batch-wide cell array
+    uint32_t cell_base;            // first cell of this structure in the batch-wide cell array: index of a 16-bit
+                                   // entry when in_lds (multiple of 8), of a 32-bit entry otherwise
     float max_r;                   // fold(0.0, max) of the radii           (lib.rs:259-262)
     float cell_size;               // probe + max_r                        (lib.rs:76)
     uint32_t n_cells;
     uint32_t atom_begin;           // first atom of the structure in input order
     uint32_t n_atoms;
     uint32_t sorted_base;          // first position of the structure in the cell-sorted arrays
-    uint32_t in_lds;               // 1: binned by k_sort_small (cells fit the LDS), 0: by the batch-wide kernels
+    uint32_t in_lds;               // 1: binned by k_sort_window (fewer than 65536 atoms; 16-bit cell starts relative
+                                   // to sorted_base), 0: by the batch-wide kernels (32-bit absolute cell starts)
     uint32_t pad;
 };
 static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
@@ -47,11 +49,14 @@ struct BatchStatus {
     uint32_t grid_too_large;  // some structure needs more than 2^31 cells
     uint32_t bad_input;       // probe + max_r <= 0 or non-finite bounds
     uint32_t deferred;        // atoms k_occlusion_fast left to the general kernel (BatchView::deferred_list)
-    uint64_t total_cells;     // cells of the batch-wide array in use (LDS-binned structures first, then the tail)
-    uint64_t tail_cell_begin; // first cell of the structures binned by the batch-wide kernels (multiple of 1024)
+    uint64_t total_cells;     // 32-bit entries of the batch-wide cell array in use (the 16-bit cell starts of the
+                              // LDS-binned structures first, two per entry, then the tail's)
+    uint64_t tail_cell_begin; // first entry of the structures binned by the batch-wide kernels (multiple of 1024)
     uint32_t tail_atom_base;  // their first position in the cell-sorted arrays (= atoms of the LDS-binned structures)
-    uint32_t pad[3];
+    uint32_t n_windows;       // entries of BatchView::windows (work list of k_sort_window)
+    uint64_t grid_cells;      // cells of all grids (statistic)
 };
+static_assert(sizeof(BatchStatus) == 48, "BatchStatus layout");
 
 struct Lattice {
     const float *x, *y, *z;  // device SoA, padded with zeros to a multiple of 64 entries
@@ -82,8 +87,10 @@ struct BatchView {
     uint32_t *sid_sorted;         // structure of the atom at cell-sorted position p
     uint32_t *cell_of, *rank_of;  // cell index / arrival rank inside the cell (binning only)
     uint32_t *deferred_list;      // atoms k_occlusion_fast left to the general kernel (BatchStatus::deferred entries)
-    uint32_t *cells;              // counts, then exclusive starts (cell_capacity + 1 entries)
+    uint32_t *cells;              // cell starts (cell_capacity + 1 entries of 32 bits; see StructGrid::cell_base)
     uint64_t cell_capacity;
+    uint2 *windows;               // (structure, window) of every k_sort_window workgroup
+    uint32_t window_capacity;     // entries of `windows` = workgroups launched (the surplus exits)
     uint32_t *scan_block_sums;
     GridSums *grid_sums;   // per 256 structures: (cells, atoms) x (LDS-binned, tail), 4 x u64
     float4 *sorted_xyzr;          // cell-sorted (x, y, z, radius)
@@ -112,7 +119,6 @@ struct OcclusionTuning {
 void launch_grid_prepare(const BatchView &b, hipStream_t stream);
 void launch_sort_lds(const BatchView &b, hipStream_t stream);
 void launch_sort_tail(const BatchView &b, hipStream_t stream);
-void launch_sort_lds_single(const BatchView &b, hipStream_t stream);
 // Which atoms (cell-sorted positions) an occlusion launch covers: the tail's binning may still be
 // running on another stream while the LDS-binned structures are processed.
 enum OcclusionPart : uint32_t {
@@ -130,11 +136,12 @@ void launch_expand_frames(const float *xyz, const float *radius, const uint64_t 
 
 constexpr uint32_t kSegmentAtoms = 4096;  // atoms per bounds workgroup
 constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
-constexpr uint32_t kLdsCells = 73728;     // cells k_sort_small bins in LDS per pass (16-bit counters, 144 KiB)
-#ifndef RSASA_MAX_LDS_WINDOWS
-#define RSASA_MAX_LDS_WINDOWS 3
-#endif
-constexpr uint32_t kMaxLdsWindows = RSASA_MAX_LDS_WINDOWS;  // larger grids go to the batch-wide kernels: one
-                                                            // workgroup walking many windows is the slowest in the launch
+constexpr uint32_t kWindowCells = 36864;  // cells one k_sort_window workgroup bins (16-bit counters, 72 KiB: two per CU)
+constexpr uint32_t kLdsMaxAtoms = 65536;  // structures with fewer atoms are binned in LDS (16-bit positions)
+
+// 16-bit entries a structure of n_cells cells takes in the cell array: its cells, the end marker,
+// padding to whole 16-byte vectors.
+__host__ __device__ constexpr uint32_t lds_cell_slots(uint32_t n_cells) { return (n_cells + 1u + 7u) & ~7u; }
+__host__ __device__ constexpr uint32_t grid_windows(uint32_t n_cells) { return (n_cells + kWindowCells - 1u) / kWindowCells; }
 
 }  // namespace rsasa

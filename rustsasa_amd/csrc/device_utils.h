@@ -28,6 +28,7 @@ __device__ __forceinline__ uint32_t f2u_sat(float v)
 }
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // Orders this wave's LDS writes before its later LDS reads (same wave only).
 __device__ __forceinline__ void wave_lds_fence()
@@ -56,24 +57,23 @@ __device__ __forceinline__ T wave_incl_scan(T v)
 }
 
 // Inclusive scan over a workgroup of kWave * NW threads; returns the inclusive
-// value and the workgroup total.  `smem` holds NW words.
-template <int NW, typename T>
-__device__ __forceinline__ T block_incl_scan(T v, T *smem, T &total)
+// value and the workgroup total.  `smem` holds NW words.  Every wave scans the NW wave totals
+// itself (lane = wave): a handful of registers, where a loop over the totals keeps NW values and
+// NW lane masks alive around the caller's loops.
+template <int NW>
+__device__ __forceinline__ uint32_t block_incl_scan(uint32_t v, uint32_t *smem, uint32_t &total)
 {
-    const uint32_t l = lane_id(), w = threadIdx.x / kWave;
-    T inc = wave_incl_scan(v);
+    static_assert(NW <= kWave, "one lane per wave");
+    const uint32_t l = lane_id();
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const uint32_t inc = wave_incl_scan(v);
     __syncthreads();
     if (l == kWave - 1) smem[w] = inc;
     __syncthreads();
-    T off = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        T s = smem[i];
-        if ((uint32_t)i < w) off += s;
-        tot += s;
-    }
-    total = tot;
-    return inc + off;
+    const uint32_t s = l < (uint32_t)NW ? smem[l] : 0u;
+    const uint32_t sc = wave_incl_scan(s);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)sc, kWave - 1);
+    return inc + (uint32_t)__builtin_amdgcn_readlane((int)(sc - s), (int)w);
 }
 
 __device__ __forceinline__ bool batch_aborted(const BatchStatus *st)
@@ -91,6 +91,14 @@ __device__ __forceinline__ void cell_coords(const StructGrid &g, float x, float 
     cz = min(f2u_sat((z - g.min_z) * g.inv_cell), g.dim_z - 1u);
 }
 
+
+// Entry `idx` of the batch-wide cell array (StructGrid::cell_base + a cell of the structure): the
+// cell-sorted position of the cell's first atom - relative to the structure's first sorted atom
+// (16-bit entries) for LDS-binned structures, absolute (32-bit entries) for the others.
+__device__ __forceinline__ uint32_t load_cell_start(const uint32_t *cells, uint32_t idx, bool rel16)
+{
+    return rel16 ? (uint32_t)reinterpret_cast<const uint16_t *>(cells)[idx] : cells[idx];
+}
 
 // 64-bit atom id -> 32 bits.  Only used as a filter: ids whose folds differ are different; equal
 // folds are decided on the full ids (the general kernel).

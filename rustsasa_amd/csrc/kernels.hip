@@ -2,7 +2,8 @@
 //
 // Pipeline for one batch of independent structures (all on one stream):
 //   k_init_acc -> k_bounds -> k_grid_params/scan/bases    per-structure cell grids
-//   k_zero_cells -> k_cell_hist -> k_scan_* -> k_scatter  counting sort into cells
+//   k_sort_window                                         counting sort into cells, in LDS
+//   k_zero_cells -> k_cell_hist -> k_scan_* -> k_scatter  the same for structures of 65536 atoms or more
 //   k_occlusion                                           candidate gather + point tests
 //   k_residue_sums                                        ResidueLevel aggregation
 //
@@ -32,6 +33,8 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
         status->total_cells = 0;
         status->tail_cell_begin = 0;
         status->tail_atom_base = 0;
+        status->n_windows = 0;
+        status->grid_cells = 0;
     }
     if (s >= n_structures) return;
     const int pinf = f2ord(__int_as_float(0x7F800000)), ninf = f2ord(__int_as_float(0xFF800000));
@@ -106,17 +109,18 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
     g.n_cells = (uint32_t)nc;
     g.atom_begin = a.n_atoms ? a.first_atom : 0u;
     g.n_atoms = a.n_atoms;
-    // 16-bit LDS counters and prefixes: fewer than 65536 atoms and at most kMaxLdsWindows windows of
-    // cells -> one workgroup bins the structure in LDS (k_sort_small: small grids two workgroups
-    // per CU, larger ones window by window); else the batch-wide kernels
-    g.in_lds = (a.n_atoms >= 65536u || g.n_cells > kMaxLdsWindows * kLdsCells) ? 0u : (g.n_cells <= kLdsCells / 2 ? 1u : 2u);
+    // 16-bit LDS counters and positions: structures with fewer than 65536 atoms are binned in LDS,
+    // one k_sort_window workgroup per window of kWindowCells cells; the others by the batch-wide kernels
+    g.in_lds = a.n_atoms < kLdsMaxAtoms ? 1u : 0u;
     return g;
 }
 
 // Grids of all structures plus the exclusive scans that place each structure's cells in the
-// batch-wide cell array and its atoms in the cell-sorted arrays.  Structures whose cells fit the
-// LDS (k_sort_small) come first in both, in structure order; the others form the "tail" that the
-// batch-wide histogram / scan / scatter kernels handle.  Three small kernels:
+// batch-wide cell array and its atoms in the cell-sorted arrays.  Structures binned in LDS
+// (k_sort_window; 16-bit cell starts) come first in both, in structure order; the others form the
+// "tail" that the batch-wide histogram / scan / scatter kernels handle (32-bit cell starts).  The
+// LDS-binned structures' windows are numbered by the same scan: GridSums::atoms_s carries the atoms
+// in its low and the windows in its high 32 bits (a batch has fewer than 2^32 atoms).  Three small kernels:
 //   k_grid_params  (one thread per structure)  grid + per-workgroup sums of (cells, atoms) x (LDS, tail)
 //   k_grid_scan    (one workgroup)             exclusive scan of those sums, totals -> BatchStatus
 //   k_grid_bases   (one thread per structure)  cell_base / sorted_base of every structure
@@ -153,15 +157,20 @@ __global__ __launch_bounds__(256) void k_grid_params(BatchView b)
     __shared__ unsigned long long part[4][4];
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     GridSums v = {0, 0, 0, 0};
+    unsigned long long n_cells = 0;
     if (s < b.n_structures) {
         bool bad = false, too_large = false;
         const StructGrid g = make_grid(b.acc[s], b.probe, bad, too_large);
         b.grids[s] = g;  // cell_base / sorted_base follow in k_grid_bases
         if (bad) b.status->bad_input = 1u;
         if (too_large) b.status->grid_too_large = 1u;
-        if (g.in_lds) { v.cells_s = g.n_cells; v.atoms_s = g.n_atoms; }
+        if (g.in_lds) { v.cells_s = lds_cell_slots(g.n_cells); v.atoms_s = g.n_atoms | ((unsigned long long)grid_windows(g.n_cells) << 32); }
         else { v.cells_l = g.n_cells; v.atoms_l = g.n_atoms; }
+        n_cells = g.n_cells;
     }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) n_cells += __shfl_xor(n_cells, d, kWave);
+    if (lane_id() == 0 && n_cells) atomicAdd((unsigned long long *)&b.status->grid_cells, n_cells);
     const GridSums tot = block_scan_sums<4>(v, part);
     if (threadIdx.x == 0) b.grid_sums[blockIdx.x] = tot;
 }
@@ -185,15 +194,18 @@ __global__ __launch_bounds__(NW * kWave) void k_grid_scan(BatchView b, uint32_t 
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        // the tail starts on a 1024-cell boundary (vector accesses of the scan kernels) and leaves
-        // at least one entry after the LDS-binned cells for their end marker.  Cell indices are
-        // 32-bit: a batch is limited to 2^32 - 16 cells, more is reported as an overflow.
-        const unsigned long long tail_begin = (carry.cells_s + 1ull + 1023ull) & ~1023ull;
+        // the LDS-binned structures' 16-bit cell starts come first, two per 32-bit entry; the tail
+        // starts on a 1024-entry boundary (vector accesses of the scan kernels).  Cell indices are
+        // 32-bit: a batch is limited to 2^32 - 16 entries of either kind, more is reported as an overflow.
+        const unsigned long long tail_begin = (carry.cells_s / 2ull + 1023ull) & ~1023ull;
         const unsigned long long total = tail_begin + carry.cells_l;
+        const unsigned long long n_windows = carry.atoms_s >> 32;
         b.status->total_cells = total;
         b.status->tail_cell_begin = tail_begin;
         b.status->tail_atom_base = (uint32_t)carry.atoms_s;
-        b.status->overflow = (total > b.cell_capacity || total > 0xFFFFFFF0ull) ? 1u : 0u;
+        b.status->n_windows = (uint32_t)min(n_windows, 0xFFFFFFFFull);
+        b.status->overflow = (total > b.cell_capacity || total > 0xFFFFFFF0ull || carry.cells_s > 0xFFFFFFF0ull ||
+                              n_windows > b.window_capacity) ? 1u : 0u;
     }
 }
 
@@ -208,140 +220,256 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
         na = b.grids[s].n_atoms;
         in_lds = b.grids[s].in_lds != 0u;
     }
-    GridSums v = {in_lds ? ncells : 0u, in_lds ? 0u : ncells, in_lds ? na : 0u, in_lds ? 0u : na};
+    const uint32_t slots = lds_cell_slots(ncells), n_win = grid_windows(ncells);
+    const unsigned long long own = na | ((unsigned long long)n_win << 32);
+    GridSums v = {in_lds ? slots : 0u, in_lds ? 0u : ncells, in_lds ? own : 0ull, in_lds ? 0u : na};
     (void)block_scan_sums<4>(v, part);
     if (s < b.n_structures) {
         const GridSums base = b.grid_sums[blockIdx.x];
-        const unsigned long long cb = in_lds ? base.cells_s + v.cells_s - ncells
+        const unsigned long long cb = in_lds ? base.cells_s + v.cells_s - slots
                                              : b.status->tail_cell_begin + base.cells_l + v.cells_l - ncells;
+        const unsigned long long as = base.atoms_s + v.atoms_s - own;  // atoms | windows << 32 before this structure
         b.grids[s].cell_base = (uint32_t)(cb > 0xFFFFFFFFull ? 0xFFFFFFFFull : cb);
-        b.grids[s].sorted_base = (uint32_t)(in_lds ? base.atoms_s + v.atoms_s - na
-                                                   : b.status->tail_atom_base + base.atoms_l + v.atoms_l - na);
+        b.grids[s].sorted_base = in_lds ? (uint32_t)as : (uint32_t)(b.status->tail_atom_base + base.atoms_l + v.atoms_l - na);
+        if (in_lds && !batch_aborted(b.status)) {
+            const uint32_t w0 = (uint32_t)(as >> 32);
+            for (uint32_t w = 0; w < n_win; w++) b.windows[w0 + w] = make_uint2(s, w);
+        }
     }
 }
 
-// Counting sort of ONE structure whose cells fit the LDS: 16-bit counters (two cells per word),
-// histogram with LDS atomics, in-place exclusive scan, then the cell starts and the sorted atoms
-// go to global memory.  Replaces k_zero_cells / k_cell_hist / k_scan_* / k_scatter for that
-// structure: the batch-wide cell array is written once and never read back.
-template <uint32_t TIER>  // 1: up to kLdsCells / 2 cells (two workgroups per CU), 2: any number of cells
-__global__ __launch_bounds__(1024) void k_sort_small(BatchView b)
+// Counting sort of ONE window (kWindowCells consecutive cells) of one structure in LDS: 16-bit
+// counters (two cells per word), histogram with LDS atomics, in-place exclusive scan, then the
+// cell starts and the window's sorted atoms go to global memory.  Replaces k_zero_cells /
+// k_cell_hist / k_scan_* / k_scatter for structures with fewer than 65536 atoms: the cell array is
+// written once - as 16-bit positions relative to the structure's first sorted atom, half the
+// bytes of absolute ones - and never read back.  The windows of a structure are independent
+// workgroups (BatchView::windows): each looks at all atoms of the structure, counts the ones in
+// earlier windows (they precede its own in the sorted order) and bins its own.
+//
+// The sorted records leave through the LDS.  A scattered store costs the CU's memory pipeline one
+// cycle per lane (64 lines per instruction), five arrays make five of them per atom, and two
+// workgroups per CU do not hide that.  So every atom first takes its position from its cell's
+// cursor (cell and position stay in registers, kSlots atoms per thread), and once the cursors
+// are dead the counter memory stages the records by position: they go out as whole lines.  Atoms
+// beyond the registers' share (structures with more than kSlots * 1024 atoms) keep their position
+// in memory (rank_of); positions beyond the staging area (a window with more atoms than it
+// holds) are stored directly.
+__global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b)
 {
-    if (batch_aborted(b.status)) return;
-    constexpr uint32_t kWindow = kLdsCells / (TIER == 1 ? 2 : 1);  // cells binned per pass
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindow / 2];
+    constexpr int kSlots = 8;                              // atoms per thread with (cell, position) in registers
+    constexpr int kChunk = 4;                              // slots whose loads are in flight together
+    constexpr uint32_t kStage = kWindowCells * 2u / 32u;   // 32-byte records the counter memory stages
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindowCells / 2 + 4];
     __shared__ uint32_t smem32[16];
-    const uint32_t s = blockIdx.x;
+    __shared__ uint32_t s_below;
+    if (batch_aborted(b.status) || blockIdx.x >= b.status->n_windows) return;
+    const uint2 job = b.windows[blockIdx.x];
+    const uint32_t s = job.x, c0 = job.y * kWindowCells;
     const StructGrid g = b.grids[s];
-    if (g.in_lds != TIER) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
     const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z, *__restrict__ pr = b.radius;
     const uint64_t *__restrict__ pid = b.id;
-    uint32_t *__restrict__ cell_of = b.cell_of, *__restrict__ rank_of = b.rank_of;
-    // A grid larger than the LDS window is binned window by window (cells [c0, c0 + kWindow)):
-    // atoms outside the window are skipped and come back in their own pass.  `placed` = atoms of
-    // the windows before, i.e. the first sorted position of this window's atoms.
-    uint32_t placed = 0;
-    for (uint32_t c0 = 0; c0 < g.n_cells; c0 += kWindow) {
-        const uint32_t n_cells = min(kWindow, g.n_cells - c0), n_words = (n_cells + 1u) >> 1;
-        const bool first = c0 == 0u;
-        {
-            uint4 *z4 = reinterpret_cast<uint4 *>(s_cnt);
-            for (uint32_t i = tid; i < (n_words + 3u) / 4u; i += 1024u) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        __syncthreads();
-        // spatial_grid.rs:53-62; the atomic's return value is the atom's slot inside its cell.
-        // Four atoms per trip, loads first: one workgroup per CU has little else to hide latency with.
-        for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
-            uint32_t c[4], old[4];
-            if (first) {
-                float x[4], y[4], z[4];
+    uint32_t *__restrict__ rank_of = b.rank_of;  // sorted position of the atoms without a slot
+    const uint32_t dim_xy = g.dim_x * g.dim_y;
+    uint4 *stage = reinterpret_cast<uint4 *>(s_cnt);
+    const uint32_t n_cells = min(kWindowCells, g.n_cells - c0), n_words = (n_cells + 1u) >> 1;
+    const bool last_window = c0 + n_cells == g.n_cells;
+
+    for (uint32_t i = tid; i < (n_words + 1u + 3u) / 4u; i += 1024u) stage[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) s_below = 0;
+    // ---- cells of the structure's first kSlots * 1024 atoms (slot k of a thread: atom a0 + tid + 1024 k) ----
+    uint32_t rcell[kSlots], rpos[kSlots];
+    uint32_t below = 0;  // atoms in earlier windows (wave-uniform count)
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
-                    x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
-                }
+    for (int k0 = 0; k0 < kSlots; k0 += kChunk) {
+        float x[kChunk], y[kChunk], z[kChunk];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t cx, cy, cz;
-                    cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
-                    c[k] = cx + cy * g.dim_x + cz * g.dim_x * g.dim_y;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++) c[k] = cell_of[min(i0 + 1024u * k, a1 - 1u)];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t lc = c[k] - c0;
-                old[k] = 0;
-                if (i0 + 1024u * k < a1 && lc < n_cells) old[k] = atomicAdd(&s_cnt[lc >> 1], 1u << ((lc & 1u) * 16u));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t i = i0 + 1024u * k, lc = c[k] - c0;
-                if (i < a1) {
-                    if (first) cell_of[i] = c[k];
-                    if (lc < n_cells) rank_of[i] = (old[k] >> ((lc & 1u) * 16u)) & 0xFFFFu;
-                }
+        for (int k = 0; k < kChunk; k++) {
+            x[k] = y[k] = z[k] = 0.f;
+            if (1024u * (k0 + k) < g.n_atoms) {
+                const uint32_t i = min(a0 + tid + 1024u * (k0 + k), a1 - 1u);
+                x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
             }
         }
-        __syncthreads();
-        // exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive
-        // words (odd stride: no bank conflicts), sums them, the partial sums are scanned across the
-        // workgroup, and the words are rewritten as (prefix of the even cell | prefix of the odd
-        // one << 16), counted from the structure's first atom: < 65536, it has < 65536 atoms
-        const uint32_t per = ((n_words + 1023u) / 1024u) | 1u;
-        const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
-        uint32_t sum = 0;
-        for (uint32_t j = w0; j < w1; j++) {
-            const uint32_t v = s_cnt[j];
-            sum += (v & 0xFFFFu) + (v >> 16);
-        }
-        uint32_t total;
-        uint32_t running = placed + block_incl_scan<16>(sum, smem32, total) - sum;
-        for (uint32_t j = w0; j < w1; j++) {
-            const uint32_t v = s_cnt[j];
-            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-            s_cnt[j] = running | ((running + lo) << 16);
-            running += lo + hi;
-        }
-        __syncthreads();
-        // cell starts; after the last window the end marker that the last cell's run length is read from
-        const uint32_t n_write = n_cells + (c0 + n_cells == g.n_cells ? 1u : 0u);
-        for (uint32_t c = tid; c < n_write; c += 1024u) {
-            const uint32_t pre = c < n_cells ? (s_cnt[c >> 1] >> ((c & 1u) * 16u)) & 0xFFFFu : g.n_atoms;
-            b.cells[g.cell_base + c0 + c] = g.sorted_base + pre;
-        }
-        // scatter (spatial_grid.rs:70-93), four atoms per trip
-        for (uint32_t i0 = a0 + tid; i0 < a1; i0 += 4096u) {
-            uint32_t c[4], rk[4];
-            float4 v[4];
-            uint64_t id[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
-                c[k] = cell_of[i] - c0; rk[k] = rank_of[i];
-                v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
-                id[k] = pid ? pid[i] : 0ull;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t i = i0 + 1024u * k;
-                if (i < a1 && c[k] < n_cells) {
-                    const uint32_t pos = g.sorted_base + ((s_cnt[c[k] >> 1] >> ((c[k] & 1u) * 16u)) & 0xFFFFu) + rk[k];
-                    b.sorted_xyzr[pos] = v[k];
-                    b.sorted_orig[pos] = i;
-                    b.sid_sorted[pos] = s;
-                    if (pid) { b.sorted_id[pos] = id[k]; b.sorted_id32[pos] = fold_id(id[k]); }
-                }
-            }
+        for (int k = 0; k < kChunk; k++) {
+            uint32_t cx, cy, cz;
+            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+            const bool live = a0 + tid + 1024u * (k0 + k) < a1;
+            const uint32_t c = cx + cy * g.dim_x + cz * dim_xy;
+            // cell relative to the window; no atom in this slot or another window's: >= n_cells
+            rcell[k0 + k] = live ? c - c0 : 0xFFFFFFFFu;
+            rpos[k0 + k] = 0;
+            if (c0) below += (uint32_t)__popcll(ballot64(live && c < c0));
         }
-        placed += total;
-        __syncthreads();  // the counters are zeroed again for the next window
     }
-    if (g.n_cells == 0u && tid == 0u) b.cells[g.cell_base] = g.sorted_base;
+    const uint32_t a_rest = a0 + 1024u * kSlots;  // first atom without a slot
+    __syncthreads();
+    // ---- count (spatial_grid.rs:53-62) ----
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        const uint32_t lc = rcell[k];
+        if (lc < n_cells) atomicAdd(&s_cnt[lc >> 1], 1u << ((lc & 1u) * 16u));
+    }
+    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4096u) {  // four atoms per trip, loads first
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t cx, cy, cz;
+            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+            const bool live = i0 + 1024u * k < a1;
+            const uint32_t c = cx + cy * g.dim_x + cz * dim_xy, lc = c - c0;
+            if (live && lc < n_cells) atomicAdd(&s_cnt[lc >> 1], 1u << ((lc & 1u) * 16u));
+            if (c0) below += (uint32_t)__popcll(ballot64(live && c < c0));
+        }
+    }
+    if (c0 && lane_id() == 0 && below) atomicAdd(&s_below, below);
+    __syncthreads();
+    // ---- exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive
+    // words (odd stride: no bank conflicts), sums them, the partial sums are scanned across the
+    // workgroup, and the words are rewritten as (start of the even cell | start of the odd one << 16),
+    // counted from the structure's first sorted atom: < 65536, it has < 65536 atoms
+    const uint32_t placed = s_below;  // the window's first position
+    const uint32_t per = ((n_words + 1023u) / 1024u) | 1u;
+    const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
+    uint32_t sum = 0;
+    for (uint32_t j = w0; j < w1; j++) {
+        const uint32_t v = s_cnt[j];
+        sum += (v & 0xFFFFu) + (v >> 16);
+    }
+    uint32_t total;
+    uint32_t running = placed + block_incl_scan<16>(sum, smem32, total) - sum;
+    for (uint32_t j = w0; j < w1; j++) {
+        const uint32_t v = s_cnt[j];
+        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+        s_cnt[j] = running | ((running + lo) << 16);
+        running += lo + hi;
+    }
+    // the end marker the last cell's run length is read from: with an odd number of cells it is
+    // the upper half of the last word already (an empty cell's start), else the word after
+    if (last_window && tid == 0 && (n_cells & 1u) == 0u) s_cnt[n_words] = g.n_atoms;
+    __syncthreads();
+    // ---- cell starts: the words as they are, eight cells per store ----
+    {
+        uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(b.cells) + g.cell_base + c0);
+        const uint32_t n16 = n_cells + (last_window ? 1u : 0u);
+        for (uint32_t i = tid; i < (n16 + 7u) / 8u; i += 1024u) out[i] = stage[i];
+    }
+    __syncthreads();  // the starts turn into the cells' cursors
+    // ---- positions (spatial_grid.rs:70-93): an atom takes the next free position of its cell.
+    // The order inside a cell is the order of arrival - the results do not depend on it.
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        const uint32_t lc = rcell[k];
+        if (lc < n_cells) {
+            const uint32_t sh = (lc & 1u) * 16u;
+            rpos[k] = (atomicAdd(&s_cnt[lc >> 1], 1u << sh) >> sh) & 0xFFFFu;
+        }
+    }
+    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4096u) {  // atoms without a slot: position through memory
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + 1024u * k;
+            uint32_t cx, cy, cz;
+            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+            const uint32_t lc = cx + cy * g.dim_x + cz * dim_xy - c0;
+            if (i < a1 && lc < n_cells) {
+                const uint32_t sh = (lc & 1u) * 16u;
+                rank_of[i] = (atomicAdd(&s_cnt[lc >> 1], 1u << sh) >> sh) & 0xFFFFu;
+            }
+        }
+    }
+    __syncthreads();  // the cursors are dead: their memory stages the records, by position
+    const uint32_t out0 = g.sorted_base + placed;  // this window's atoms are [out0, out0 + total)
+    const uint32_t n_staged = min(total, kStage);
+    // 32 bytes per atom: (x, y, z, radius) and (input index, id fold, id)
+#pragma unroll
+    for (int k0 = 0; k0 < kSlots; k0 += kChunk) {
+        if (1024u * k0 < g.n_atoms) {
+            float4 v[kChunk];
+            uint64_t id[kChunk];
+#pragma unroll
+            for (int k = 0; k < kChunk; k++) {
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                id[k] = 0ull;
+                if (rcell[k0 + k] < n_cells) {
+                    const uint32_t i = a0 + tid + 1024u * (k0 + k);
+                    v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
+                    if (pid) id[k] = pid[i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kChunk; k++) {
+                const uint32_t rel = rpos[k0 + k] - placed, i = a0 + tid + 1024u * (k0 + k);
+                if (rcell[k0 + k] < n_cells) {
+                    if (rel < kStage) {
+                        stage[2u * rel] = __builtin_bit_cast(uint4, v[k]);
+                        stage[2u * rel + 1u] = make_uint4(i, fold_id(id[k]), (uint32_t)id[k], (uint32_t)(id[k] >> 32));
+                    } else {
+                        const uint32_t p = g.sorted_base + rpos[k0 + k];
+                        b.sorted_xyzr[p] = v[k];
+                        b.sorted_orig[p] = i;
+                        if (pid) { b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
+                    }
+                }
+            }
+        }
+    }
+    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4096u) {
+        float4 v[4];
+        uint64_t id[4];
+        uint32_t pos[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+            pos[k] = rank_of[i];  // (another window's atom: not ours to read, ignored below)
+            v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
+            id[k] = pid ? pid[i] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t i = i0 + 1024u * k;
+            uint32_t cx, cy, cz;
+            cell_coords(g, v[k].x, v[k].y, v[k].z, cx, cy, cz);
+            const uint32_t lc = cx + cy * g.dim_x + cz * dim_xy - c0;
+            if (i < a1 && lc < n_cells) {
+                const uint32_t rel = pos[k] - placed;
+                if (rel < kStage) {
+                    stage[2u * rel] = __builtin_bit_cast(uint4, v[k]);
+                    stage[2u * rel + 1u] = make_uint4(i, fold_id(id[k]), (uint32_t)id[k], (uint32_t)(id[k] >> 32));
+                } else {
+                    const uint32_t p = g.sorted_base + pos[k];
+                    b.sorted_xyzr[p] = v[k];
+                    b.sorted_orig[p] = i;
+                    if (pid) { b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < n_staged; j += 1024u) {
+        const uint4 q = stage[2u * j + 1u];
+        b.sorted_xyzr[out0 + j] = __builtin_bit_cast(float4, stage[2u * j]);
+        b.sorted_orig[out0 + j] = q.x;
+        if (pid) {
+            b.sorted_id32[out0 + j] = q.y;
+            b.sorted_id[out0 + j] = (uint64_t)q.z | ((uint64_t)q.w << 32);
+        }
+    }
+    for (uint32_t j = tid; j < total; j += 1024u) b.sid_sorted[out0 + j] = s;
 }
 
 // ---- batch-wide path for the structures of the tail (cells do not fit the LDS) ----
@@ -492,19 +620,12 @@ void launch_grid_prepare(const BatchView &b, hipStream_t stream)
     hipLaunchKernelGGL(k_grid_bases, dim3(n_parts), dim3(256), 0, stream, b);
 }
 
-// Binning of the structures whose grid fits the LDS (one workgroup each).
+// Binning of the structures with fewer than 65536 atoms: one workgroup per window of cells.  The
+// work list is written on the device (k_grid_bases); `window_capacity` workgroups are launched and
+// the surplus exits.
 void launch_sort_lds(const BatchView &b, hipStream_t stream)
 {
-    if (!b.n_structures) return;
-    hipLaunchKernelGGL(k_sort_small<1>, dim3(b.n_structures), dim3(1024), 0, stream, b);
-    hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
-}
-
-// Small host-side batches (context.cpp, run_small_host_batch): the grids were computed on the
-// host and every structure is marked for the windowed LDS kernel.
-void launch_sort_lds_single(const BatchView &b, hipStream_t stream)
-{
-    if (b.n_structures) hipLaunchKernelGGL(k_sort_small<2>, dim3(b.n_structures), dim3(1024), 0, stream, b);
+    if (b.window_capacity) hipLaunchKernelGGL(k_sort_window, dim3(b.window_capacity), dim3(1024), 0, stream, b);
 }
 
 // Batch-wide binning of the other structures (the tail).  Independent of launch_sort_lds: the
