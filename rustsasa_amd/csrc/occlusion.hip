@@ -75,13 +75,15 @@ void launch_fast2(bool half1, uint32_t n_blocks, hipStream_t stream, const OccAr
     else hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
 }
 
-template <int NT, bool MULTI>
-void launch_mx(bool has_id, bool rem, uint32_t n_blocks, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
+// NW waves per workgroup, each with up to atoms_per_wave atoms
+template <int NT, bool MULTI, int NW>
+void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
 {
-    if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
-    else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
-    else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
-    else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI>), dim3(n_blocks), dim3(256), lds_bytes, stream, a3);
+    const uint32_t n_blocks = cdiv(n_atoms, NW * a3.atoms_per_wave);
+    if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+    else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+    else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+    else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
 }
 
 void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
@@ -141,16 +143,23 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // group-union sweep + matrix-core point tests: 64 atoms per wave
             // 64 atoms per wave once that still leaves about four rounds of waves (256 CUs x 4 SIMDs x 7
             // waves resident) - fewer (down to 8) for smaller batches, where the last, partly filled round
-            // and, for single structures, the time of one wave set the time of the call
+            // and, for single structures, the time of one wave set the time of the call.  With many
+            // points an atom is a microsecond of work and a wave's atoms share less of it: 16 rounds.
+            const uint32_t rounds = lat.n_fused > 128u ? 16u : 4u;
             uint32_t apw = kMxAtoms;
             if (tune.atoms_per_wave > 0) apw = min(tune.atoms_per_wave, kMxAtoms);
-            else while (apw > 8u && (uint64_t)apw * (256u * 4u * 7u * 4u) > b.n_atoms) apw >>= 1;
+            else while (apw > 8u && (uint64_t)apw * (256u * 4u * 7u * rounds) > b.n_atoms) apw >>= 1;
             a3.atoms_per_wave = apw;
-            const uint32_t mx_blocks = cdiv(b.n_atoms, 4u * apw);
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
-            if (lat.n_fused <= 96u) launch_mx<6, false>(b.id != nullptr, rem, mx_blocks, 24u * 96u, stream, a3);
-            else if (lat.n_fused <= 128u) launch_mx<8, false>(b.id != nullptr, rem, mx_blocks, 24u * 128u, stream, a3);
-            else launch_mx<6, true>(b.id != nullptr, rem, mx_blocks, 24u * 96u * cdiv(lat.n_fused, 96u), stream, a3);
+            const bool has_id = b.id != nullptr;
+            const uint32_t table = 24u * 128u * cdiv(lat.n_fused, 128u);  // (groups of 128 points)
+            if (lat.n_fused <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u, stream, a3);
+            else if (lat.n_fused <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u, stream, a3);
+            // more points: the waves per workgroup that keep most waves on a CU (160 KB of LDS: the
+            // table once per workgroup, ~4.7 KB per wave)
+            else if (table <= 8192u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, table, stream, a3);
+            else if (table <= 24576u) launch_mx<8, true, 12>(has_id, rem, b.n_atoms, table, stream, a3);
+            else launch_mx<8, true, 8>(has_id, rem, b.n_atoms, table, stream, a3);
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }
