@@ -571,18 +571,22 @@ def test_fast_kernel_defers_dense_atoms_inside_a_mixed_batch(ctx):
 
 @pytest.mark.parametrize("overlap", ["0", "1"])
 def test_grid_build_paths_mixed(overlap, monkeypatch):
-    """(overlap = 1: the tail's binning runs on the context's side stream next to the occlusion
-    launch over the LDS-binned structures.)  Cell binning has three routes: one workgroup per structure with 16-bit LDS counters (two
-    size tiers), and the batch-wide histogram / scan / scatter for structures with more than
-    73 728 cells or 65 535 atoms.  One batch with all of them, interleaved, plus empty structures."""
+    """Cell binning has two routes: one workgroup per window of 36 864 cells with 16-bit LDS counters
+    (any number of windows; 16-bit cell starts) for structures with fewer than 65 536 atoms, and the
+    batch-wide histogram / scan / scatter for the others (32-bit cell starts).  One batch with both,
+    interleaved: one window, several, hundreds (a sparse structure: the cell array has to grow and
+    the batch runs again), more atoms than a workgroup's registers hold, empty structures.
+    (overlap = 1: the batch-wide binning runs on the context's side stream next to the occlusion
+    launch over the LDS-binned structures.)"""
     rng = np.random.default_rng(17)
     parts = []
-    # tier 1 (compact), tier 2 (elongated: ~50 k cells), windowed (very elongated), tail by cells, tail by atoms
     parts.append(rng.uniform(0, 30, size=(900, 3)))
     parts.append(rng.uniform(0, 1, size=(700, 3)) * np.array([900.0, 40.0, 40.0]))
     parts.append(np.zeros((0, 3)))
-    parts.append(rng.uniform(0, 1, size=(800, 3)) * np.array([2500.0, 45.0, 45.0]))     # 3 LDS windows
-    parts.append(rng.uniform(0, 1, size=(400, 3)) * np.array([9000.0, 60.0, 60.0]))     # > 16 windows: batch-wide
+    parts.append(rng.uniform(0, 1, size=(800, 3)) * np.array([2500.0, 45.0, 45.0]))     # 6 windows
+    parts.append(rng.uniform(0, 1, size=(400, 3)) * np.array([9000.0, 60.0, 60.0]))     # 30 windows
+    parts.append(rng.uniform(0, 1, size=(300, 3)) * np.array([30000.0, 100.0, 100.0]))  # 9 M cells: 250 windows
+    parts.append(rng.uniform(0, 70, size=(20000, 3)))                                   # 20 000 atoms, 3 windows
     parts.append(rng.uniform(0, 25, size=(500, 3)))
     parts.append(rng.uniform(0, 95, size=(70000, 3)))
     parts.append(np.zeros((0, 3)))
