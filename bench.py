@@ -45,8 +45,8 @@ PMC_FILE = os.path.join("profiles", "pmc_occlusion.json")
 def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=100)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--structures", type=int, default=None,
                    help="structures of the proteome (default: all 4 363)")
     p.add_argument("--workload", choices=["proteome", "uniform1m"], default="proteome")
@@ -55,7 +55,7 @@ def parse_args(argv=None):
     p.add_argument("--n-points", type=int, default=None)
     p.add_argument("--cpu-seconds", type=float, default=15.0,
                    help="target wall time of the CPU baseline sample (0 disables it and the parity diff)")
-    p.add_argument("--h2h-steps", type=int, default=5,
+    p.add_argument("--h2h-steps", type=int, default=10,
                    help="timed steps of the host-to-host leg (0 disables it)")
     p.add_argument("--weak-steps", type=int, default=5,
                    help="timed steps of the secondary weak-scaling measurement at N > 1 (0 disables it)")
