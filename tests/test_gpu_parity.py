@@ -605,6 +605,44 @@ def test_grid_build_paths_mixed(overlap, monkeypatch):
     assert np.array_equal(atom, want)
 
 
+@pytest.mark.parametrize("dims_z, n_cells", [(16, 36864), (32, 73728)])
+def test_grid_of_exactly_whole_windows(dims_z, n_cells):
+    """A grid of exactly one / two windows of 36 864 cells: the last window is full and its end
+    marker is the word after the window's cells (kernels.hip, k_sort_window)."""
+    rng = np.random.default_rng(dims_z)
+    # cell size 1.4 + 1.6 = 3.0; dims = ceil(range / 3 + 2) + 1 = 48, 48, dims_z
+    box = np.array([134.0, 134.0, 38.0 if dims_z == 16 else 86.0])
+    xyz = rng.uniform(0, 1, size=(6000, 3)) * box
+    xyz[0] = 0.0
+    xyz[1] = box
+    xyz = xyz.astype(np.float32)
+    r = np.full(len(xyz), 1.6, np.float32)
+    so = np.array([0, len(xyz)], np.uint32)
+    b = bw.Batch(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), r, np.arange(len(xyz), dtype=np.uint64), so, so)
+    import rustsasa_amd
+    with rustsasa_amd.Context(0) as c:
+        c.enable_timing(True)
+        atom, _, _ = _device_run(c, b, want_res=False)
+        assert c.timings()["n_cells"] == n_cells
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, so, PROBE, 100, 8, threads=8)
+    assert np.array_equal(atom, want)
+
+
+@pytest.mark.parametrize("n_atoms", [65535, 65536])
+def test_largest_structure_binned_in_lds_and_smallest_that_is_not(n_atoms):
+    """65 535 atoms: 16-bit positions, k_sort_window; 65 536: the batch-wide kernels."""
+    rng = np.random.default_rng(n_atoms)
+    xyz = rng.uniform(0, 110, size=(n_atoms, 3)).astype(np.float32)
+    r = rng.uniform(1.2, 2.0, n_atoms).astype(np.float32)
+    so = np.array([0, n_atoms], np.uint32)
+    b = bw.Batch(xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), r, np.arange(n_atoms, dtype=np.uint64), so, so)
+    import rustsasa_amd
+    with rustsasa_amd.Context(0) as c:
+        atom, _, _ = _device_run(c, b, want_res=False)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, so, PROBE, 100, 8, threads=8)
+    assert np.array_equal(atom, want)
+
+
 def test_many_tiny_structures(ctx):
     """70 000 structures of 1-3 atoms: the grid placement scan runs over several chunks of
     per-workgroup sums, every structure is its own LDS-binned grid."""
