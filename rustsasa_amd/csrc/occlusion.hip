@@ -145,9 +145,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // waves resident) - fewer (down to 8) for smaller batches, where the last, partly filled round
             // and, for single structures, the time of one wave set the time of the call.  With many
             // points an atom is a microsecond of work and a wave's atoms share less of it: 16 rounds.
-            const uint32_t rounds = lat.n_fused > 128u ? 16u : 4u;
-            uint32_t apw = kMxAtoms;
-            if (tune.atoms_per_wave > 0) apw = min(tune.atoms_per_wave, kMxAtoms);
+            const bool multi = lat.n_fused > 128u;
+            const uint32_t rounds = multi ? 16u : 4u, apw_max = multi ? kMxAtomsMulti : kMxAtoms;
+            uint32_t apw = apw_max;
+            if (tune.atoms_per_wave > 0) apw = min(tune.atoms_per_wave, apw_max);
             else while (apw > 8u && (uint64_t)apw * (256u * 4u * 7u * rounds) > b.n_atoms) apw >>= 1;
             a3.atoms_per_wave = apw;
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
@@ -156,10 +157,11 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             if (lat.n_fused <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u, stream, a3);
             else if (lat.n_fused <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u, stream, a3);
             // more points: the waves per workgroup that keep most waves on a CU (160 KB of LDS: the
-            // table once per workgroup, ~4.7 KB per wave)
+            // table once per workgroup, ~3.2 KB per wave).  Multiples of four only: 9 or 14 waves per
+            // workgroup spread unevenly over the four SIMDs and measured 18 % slower.
             else if (table <= 8192u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, table, stream, a3);
-            else if (table <= 24576u) launch_mx<8, true, 12>(has_id, rem, b.n_atoms, table, stream, a3);
-            else launch_mx<8, true, 8>(has_id, rem, b.n_atoms, table, stream, a3);
+            else if (table <= 24576u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, table, stream, a3);   // 3 x 8 waves
+            else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, table, stream, a3);                        // 2 x 12 waves
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }
