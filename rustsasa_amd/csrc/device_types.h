@@ -85,7 +85,8 @@ struct BatchView {
     StructGrid *grids;
     uint32_t *sid;                // structure of input atom i
     uint32_t *sid_sorted;         // structure of the atom at cell-sorted position p
-    uint32_t *cell_of, *rank_of;  // cell index / arrival rank inside the cell (binning only)
+    uint32_t *cell_of, *rank_of;  // binning only.  Batch-wide route: cell index / arrival rank inside the cell;
+                                  // k_sort_window: rank_of = sorted position of the atoms a workgroup's registers do not hold
     uint32_t *deferred_list;      // atoms k_occlusion_fast left to the general kernel (BatchStatus::deferred entries)
     uint32_t *cells;              // cell starts (cell_capacity + 1 entries of 32 bits; see StructGrid::cell_base)
     uint64_t cell_capacity;
