@@ -104,6 +104,8 @@ def main():
                "--workers", str(args.workers), "--devices", str(args.devices)]
         p = subprocess.run(cmd, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr[-500:]
+        if os.environ.get("RSASA_FILES_TRACE"):
+            sys.stderr.write(p.stderr[-3000:])
         r = json.loads(p.stdout)
         r.pop("results")
         if best is None or r["total_s"] < best["total_s"]:
