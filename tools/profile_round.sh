@@ -26,6 +26,6 @@ python3 tools/pmc_summary.py "$out/pmcu_*/**/*counter_collection.csv" > $out/pmc
 rm -rf $out/pmcu_a
 python3 bench.py --workload uniform1m --cpu-seconds 0 --h2h-steps 0 > $out/u1m.log 2>&1; tail -1 $out/u1m.log > $out/bench_uniform1m.json
 python3 tools/bench_single.py 2>/dev/null > $out/single_and_pcie.json
-python3 tools/bench_files.py --files 1500 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json
+python3 tools/bench_files.py --files 4363 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json
 rm -rf $out/trace $out/pmc_a $out/pmc_b $out/pmc_fetch $out/pmc_write $out/pmc_tcc
 ls -la $out; cat $out/bench.json; cat $out/bench_under_rocprof.json; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc.txt
