@@ -219,12 +219,6 @@ std::string element_from_name(const std::string &name)
     return "";
 }
 
-std::string field(const std::string &line, size_t from, size_t to)  // 1-based inclusive columns
-{
-    if (line.size() < from) return "";
-    return trim(line.substr(from - 1, std::min(to, line.size()) - from + 1));
-}
-
 // Decimal text -> double.  Plain decimals with at most 15 significant digits (every PDB
 // %8.3f field, typical mmCIF Cartn values) take Clinger's exact fast path: an integer below
 // 2^53 divided by a power of ten below 10^22 is one correctly rounded IEEE division, so the
@@ -263,17 +257,19 @@ double parse_decimal(const char *p, size_t n)
     return std::strtod(std::string(b, (size_t)(e - b)).c_str(), nullptr);
 }
 
-inline double column_decimal(const std::string &line, size_t from, size_t to, double missing)
+template <typename Line>
+inline double column_decimal(const Line &line, size_t from, size_t to, double missing)
 {
     if (line.size() < from) return missing;
     const size_t len = std::min(to, line.size()) - from + 1;
     const char *p = line.data() + from - 1;
-    bool blank = true;
-    for (size_t i = 0; i < len; i++) blank = blank && (p[i] == ' ');
-    return blank ? missing : parse_decimal(p, len);
+    size_t i = 0;
+    while (i < len && p[i] == ' ') i++;
+    return i == len ? missing : parse_decimal(p + i, len - i);  // (a blank field is "missing")
 }
 
-inline long column_int(const std::string &line, size_t from, size_t to, bool *ok)
+template <typename Line>
+inline long column_int(const Line &line, size_t from, size_t to, bool *ok)
 {
     long v = 0;
     bool neg = false, any = false, good = true;
@@ -319,44 +315,120 @@ void tokenize(const std::string &line, std::vector<std::string> &out)
 
 double parse_decimal_text(const std::string &text) { return parse_decimal(text.data(), text.size()); }
 
+namespace {
+
+// A line of the input text, not copied.
+struct LineView {
+    const char *p;
+    size_t n;
+    size_t size() const { return n; }
+    const char *data() const { return p; }
+    char operator[](size_t i) const { return p[i]; }
+    bool starts_with(const char *lit) const
+    {
+        const size_t k = std::strlen(lit);
+        return n >= k && std::memcmp(p, lit, k) == 0;
+    }
+};
+
+// columns [from, to] (1-based, inclusive) without surrounding white space: begin and length
+inline std::pair<const char *, size_t> field_view(const LineView &line, size_t from, size_t to)
+{
+    if (line.n < from) return {line.p, 0};
+    const char *b = line.p + from - 1, *e = line.p + std::min(to, line.n);
+    auto space = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };  // isspace in the C locale
+    while (b < e && space(*b)) b++;
+    while (e > b && space(e[-1])) e--;
+    return {b, (size_t)(e - b)};
+}
+
+inline bool same(const std::string &s, const std::pair<const char *, size_t> &v)
+{
+    return s.size() == v.second && std::memcmp(s.data(), v.first, v.second) == 0;
+}
+
+}  // namespace
+
+// Same model as add_atom builds (chains by id, residues by (number, insertion code), conformers by
+// (name, alt-loc), searched from the back), without per-line strings: fields are views into the
+// text, and consecutive atoms of one conformer - nearly all of them - skip the searches.
 Structure Structure::from_pdb_text(const std::string &text)
 {
     Structure s;
-    std::istringstream is(text);
-    std::string line;
     bool in_first_model = true, seen_model = false;
     std::size_t counter = 0;
-    while (std::getline(is, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        if (line.rfind("MODEL", 0) == 0) {
+    size_t ci = (size_t)-1, ri = (size_t)-1, fi = (size_t)-1;  // chain / residue / conformer of the previous atom
+    const char *cur = text.data(), *const end = text.data() + text.size();
+    while (cur < end) {
+        const char *nl = (const char *)std::memchr(cur, '\n', (size_t)(end - cur));
+        const char *stop = nl ? nl : end;
+        LineView line{cur, (size_t)(stop - cur)};
+        cur = nl ? nl + 1 : end;
+        if (line.n && line.p[line.n - 1] == '\r') line.n--;
+        if (line.starts_with("MODEL")) {
             if (seen_model) in_first_model = false;
             seen_model = true;
             continue;
         }
-        if (line.rfind("ENDMDL", 0) == 0) { in_first_model = false; continue; }
-        const bool is_atom = line.rfind("ATOM  ", 0) == 0, is_het = line.rfind("HETATM", 0) == 0;
+        if (line.starts_with("ENDMDL")) { in_first_model = false; continue; }
+        const bool is_atom = line.starts_with("ATOM  "), is_het = line.starts_with("HETATM");
         if (!(is_atom || is_het) || !in_first_model) continue;
-        if (line.size() < 54) { s.warnings.push_back("short ATOM record skipped"); continue; }
-        FlatAtom a;
+        if (line.n < 54) { s.warnings.push_back("short ATOM record skipped"); continue; }
         counter++;
-        a.rec.hetero = is_het;
+        const auto name = field_view(line, 13, 16), alt = field_view(line, 17, 17), res_name = field_view(line, 18, 20),
+                   chain_id = field_view(line, 22, 22), icode = field_view(line, 27, 27), element = field_view(line, 77, 78);
+        const std::int64_t res_seq = column_int(line, 23, 26, nullptr);
+        // chain
+        if (ci == (size_t)-1 || !same(s.chains[ci].id, chain_id)) {
+            ci = (size_t)-1;
+            for (size_t k = s.chains.size(); k-- > 0;)
+                if (same(s.chains[k].id, chain_id)) { ci = k; break; }
+            if (ci == (size_t)-1) {
+                s.chains.push_back(Chain{std::string(chain_id.first, chain_id.second), {}});
+                ci = s.chains.size() - 1;
+            }
+            ri = fi = (size_t)-1;
+        }
+        Chain &chain = s.chains[ci];
+        // residue
+        if (ri == (size_t)-1 || chain.residues[ri].serial_number != res_seq || !same(chain.residues[ri].insertion_code, icode)) {
+            ri = (size_t)-1;
+            for (size_t k = chain.residues.size(); k-- > 0;)
+                if (chain.residues[k].serial_number == res_seq && same(chain.residues[k].insertion_code, icode)) { ri = k; break; }
+            if (ri == (size_t)-1) {
+                chain.residues.push_back(Residue{res_seq, std::string(icode.first, icode.second), {}});
+                ri = chain.residues.size() - 1;
+            }
+            fi = (size_t)-1;
+        }
+        Residue &res = chain.residues[ri];
+        // conformer
+        if (fi == (size_t)-1 || !same(res.conformers[fi].name, res_name) || !same(res.conformers[fi].alt_loc, alt)) {
+            fi = (size_t)-1;
+            for (size_t k = 0; k < res.conformers.size(); k++)
+                if (same(res.conformers[k].name, res_name) && same(res.conformers[k].alt_loc, alt)) { fi = k; break; }
+            if (fi == (size_t)-1) {
+                res.conformers.push_back(Conformer{std::string(res_name.first, res_name.second), std::string(alt.first, alt.second), {}});
+                fi = res.conformers.size() - 1;
+            }
+        }
+        std::vector<AtomRecord> &atoms = res.conformers[fi].atoms;
+        if (atoms.capacity() == atoms.size()) atoms.reserve(std::max<size_t>(16, 2 * atoms.size()));
+        atoms.emplace_back();
+        AtomRecord &rec = atoms.back();
+        rec.hetero = is_het;
         bool serial_ok = false;
         const long sv = column_int(line, 7, 11, &serial_ok);
-        a.rec.serial = serial_ok ? (std::size_t)sv : counter;
-        a.rec.name = field(line, 13, 16);
-        a.alt = field(line, 17, 17);
-        a.res_name = field(line, 18, 20);
-        a.chain = field(line, 22, 22);
-        a.res_seq = column_int(line, 23, 26, nullptr);
-        a.icode = field(line, 27, 27);
-        a.rec.x = column_decimal(line, 31, 38, 0.0);
-        a.rec.y = column_decimal(line, 39, 46, 0.0);
-        a.rec.z = column_decimal(line, 47, 54, 0.0);
-        a.rec.occupancy = column_decimal(line, 55, 60, 1.0);
-        a.rec.b_factor = column_decimal(line, 61, 66, 0.0);
-        a.rec.element = upper(field(line, 77, 78));
-        if (a.rec.element.empty()) a.rec.element = element_from_name(a.rec.name);
-        add_atom(s, a);
+        rec.serial = serial_ok ? (std::size_t)sv : counter;
+        rec.name.assign(name.first, name.second);
+        rec.x = column_decimal(line, 31, 38, 0.0);
+        rec.y = column_decimal(line, 39, 46, 0.0);
+        rec.z = column_decimal(line, 47, 54, 0.0);
+        rec.occupancy = column_decimal(line, 55, 60, 1.0);
+        rec.b_factor = column_decimal(line, 61, 66, 0.0);
+        rec.element.assign(element.first, element.second);
+        for (auto &c : rec.element) c = (char)std::toupper((unsigned char)c);
+        if (rec.element.empty()) rec.element = element_from_name(rec.name);
     }
     return s;
 }
