@@ -288,7 +288,7 @@ def main():
                                      residue_offsets=hro, want_atoms=want_atoms, atom_out=hatm,
                                      res_out=hres)
 
-        for _ in range(2):
+        for _ in range(5):  # (the first calls allocate the sub-batch slots and may regrow the cell array)
             h2h_step()
         h_el = timed(dist, args.h2h_steps, h2h_step)
         h_el, h_structs, _ = aggregate(dist, dev, h_el, batch.n_structures, batch.n_atoms)

@@ -8,6 +8,8 @@ import torch
 import bench_workloads as bw
 import rustsasa_amd
 b = bw.synthetic_proteome(seed=bw.PROTEOME_SEED)
+if os.environ.get("H2H_SORTED"):  # bench.py's order: largest structures first
+    b = bw.select(b, bw.shard_largest_first(np.diff(b.structure_offsets.astype(np.int64)), 1)[0])
 pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
 x, y, z, r, ids, ro = pin(b.x), pin(b.y), pin(b.z), pin(b.radius), pin(b.ids), pin(b.residue_offsets)
 out = pin(np.zeros(b.n_residues, np.float32))
