@@ -57,6 +57,8 @@ def parse_args(argv=None):
                    help="target wall time of the CPU baseline sample (0 disables it and the parity diff)")
     p.add_argument("--h2h-steps", type=int, default=10,
                    help="timed steps of the host-to-host leg (0 disables it)")
+    p.add_argument("--two-steps", type=int, default=40,
+                   help="steps of the secondary two-batches-in-flight measurement (0 = skip)")
     p.add_argument("--weak-steps", type=int, default=5,
                    help="timed steps of the secondary weak-scaling measurement at N > 1 (0 disables it)")
     p.add_argument("--no-ids", action="store_true", help="pass id = NULL (all atoms distinct)")
@@ -183,11 +185,23 @@ class DeviceRun:
         self.out_atom = torch.empty(batch.n_atoms, dtype=torch.float32, device=dev)
         self.out_res = torch.empty(batch.n_residues, dtype=torch.float32, device=dev)
 
-    def step(self, counts=None):
+    def enqueue(self, counts=None):
         self.ctx.enqueue_device(self.x, self.y, self.z, self.r, self.ids, self.batch.structure_offsets,
                                 self.out_atom, self.res_off, self.out_res, counts, PROBE,
                                 self.n_points, stream=self.stream)
+
+    def step(self, counts=None):
+        self.enqueue(counts)
         self.ctx.wait()
+
+    def twin(self, ctx, stream):
+        """The same resident inputs behind another context (own workspace, stream and outputs)."""
+        import copy
+        import torch
+        t = copy.copy(self)
+        t.ctx, t.stream = ctx, stream
+        t.out_atom, t.out_res = torch.empty_like(self.out_atom), torch.empty_like(self.out_res)
+        return t
 
 
 def timed(dist, steps, fn):
@@ -299,6 +313,38 @@ def main():
                              "over a copy-in, a compute and a copy-out stream",
                "residues_equal_hbm_run": bool(np.array_equal(hres, got_res))}
 
+    # ---- secondary: two batches in flight (a second context: own workspace and stream), batch k + 1
+    # enqueued before batch k is waited for.  The host's enqueue time and the small kernels of one
+    # batch then hide behind the other's occlusion kernel; `value` stays the one-batch-at-a-time rate
+    # whose kernel times the roofline is computed from.
+    two = None
+    if args.two_steps > 0:
+        ctx2 = rustsasa_amd.Context(local_rank)
+        s2 = torch.cuda.Stream()
+        runs = [run, run.twin(ctx2, s2.cuda_stream)]
+        for r_ in runs:
+            for _ in range(3):
+                r_.step()
+
+        def two_region():
+            k_steps = args.two_steps
+            runs[0].enqueue()
+            for i in range(1, k_steps):
+                runs[i % 2].enqueue()
+                runs[(i - 1) % 2].ctx.wait()
+            runs[(k_steps - 1) % 2].ctx.wait()
+
+        t_el = timed(dist, 1, two_region)
+        t_el, t_structs, _ = aggregate(dist, dev, t_el, batch.n_structures, batch.n_atoms)
+        same = bool(torch.equal(runs[0].out_res, runs[1].out_res))
+        two = {"value": round(t_structs * args.two_steps / t_el, 2), "unit": "structures/s",
+               "ms_per_step": round(t_el / args.two_steps * 1e3, 4), "steps": args.two_steps,
+               "definition": "the same steps with two batches in flight: two contexts (workspaces, streams) "
+                             "alternate, batch k + 1 is enqueued before batch k is waited for",
+               "outputs_equal": same}
+        del runs
+        ctx2.close()
+
     # ---- secondary: weak scaling (every rank its own proteome) ----
     weak = None
     if world > 1 and scaling == "strong" and args.weak_steps > 0:
@@ -391,6 +437,8 @@ def main():
         }
         if h2h:
             line["host_to_host"] = h2h
+        if two:
+            line["two_in_flight"] = two
         if weak:
             line["weak_scaling"] = weak
         if world == 1 and args.cpu_seconds > 0:
