@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""One-time costs on a fresh process: context creation (HIP runtime start-up), first tiny call, first and second
+256-structure call through host buffers."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 t0=time.perf_counter()
