@@ -75,7 +75,7 @@ struct rsasa_context {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool small_path = true;                       // RSASA_SMALL_PATH=0: small host batches take the general path too
     bool overlap_tail = false;                    // RSASA_OVERLAP_TAIL=1: bin the tail on the side stream, next to the first
-                                                  // occlusion launch (helped 2.5 % while the tail was large; neutral since k_sort_small walks windows)
+                                                  // occlusion launch (only batches with a structure of 65 536 atoms or more have a tail now)
     hipStream_t side_stream = nullptr;            // runs the tail's binning next to the launch stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     rsasa_timings_t timings{};
