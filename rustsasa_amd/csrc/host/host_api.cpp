@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <climits>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -177,41 +178,6 @@ std::size_t Structure::atom_count() const
 
 namespace {
 
-struct FlatAtom {
-    AtomRecord rec;
-    std::string alt, res_name, chain;
-    std::int64_t res_seq = 0;
-    std::string icode;
-};
-
-// pdbtbx-style insertion: chains by id, residues by (number, insertion code),
-// conformers by (name, alt-loc); existing entries are found searching from the back.
-void add_atom(Structure &s, const FlatAtom &a)
-{
-    Chain *chain = nullptr;
-    for (auto it = s.chains.rbegin(); it != s.chains.rend(); ++it)
-        if (it->id == a.chain) { chain = &*it; break; }
-    if (!chain) {
-        s.chains.push_back(Chain{a.chain, {}});
-        chain = &s.chains.back();
-    }
-    Residue *res = nullptr;
-    for (auto it = chain->residues.rbegin(); it != chain->residues.rend(); ++it)
-        if (it->serial_number == a.res_seq && it->insertion_code == a.icode) { res = &*it; break; }
-    if (!res) {
-        chain->residues.push_back(Residue{a.res_seq, a.icode, {}});
-        res = &chain->residues.back();
-    }
-    Conformer *conf = nullptr;
-    for (auto &c : res->conformers)
-        if (c.name == a.res_name && c.alt_loc == a.alt) { conf = &c; break; }
-    if (!conf) {
-        res->conformers.push_back(Conformer{a.res_name, a.alt, {}});
-        conf = &res->conformers.back();
-    }
-    conf->atoms.push_back(a.rec);
-}
-
 std::string element_from_name(const std::string &name)
 {
     for (unsigned char c : name)
@@ -288,29 +254,6 @@ inline long column_int(const Line &line, size_t from, size_t to, bool *ok)
     return neg ? -v : v;
 }
 
-// mmCIF tokenizer for one line: whitespace separated, '...' and "..." quoting.
-void tokenize(const std::string &line, std::vector<std::string> &out)
-{
-    out.clear();
-    size_t i = 0, n = line.size();
-    while (i < n) {
-        while (i < n && std::isspace((unsigned char)line[i])) i++;
-        if (i >= n) break;
-        if (line[i] == '\'' || line[i] == '"') {
-            const char q = line[i++];
-            size_t j = i;
-            while (j < n && !(line[j] == q && (j + 1 == n || std::isspace((unsigned char)line[j + 1])))) j++;
-            out.push_back(line.substr(i, j - i));
-            i = j + 1;
-        } else {
-            size_t j = i;
-            while (j < n && !std::isspace((unsigned char)line[j])) j++;
-            out.push_back(line.substr(i, j - i));
-            i = j;
-        }
-    }
-}
-
 }  // namespace
 
 double parse_decimal_text(const std::string &text) { return parse_decimal(text.data(), text.size()); }
@@ -342,43 +285,24 @@ inline std::pair<const char *, size_t> field_view(const LineView &line, size_t f
     return {b, (size_t)(e - b)};
 }
 
-inline bool same(const std::string &s, const std::pair<const char *, size_t> &v)
+using TextView = std::pair<const char *, size_t>;
+
+inline bool same(const std::string &s, const TextView &v)
 {
-    return s.size() == v.second && std::memcmp(s.data(), v.first, v.second) == 0;
+    return s.size() == v.second && (v.second == 0 || std::memcmp(s.data(), v.first, v.second) == 0);
 }
 
-}  // namespace
-
-// Same model as add_atom builds (chains by id, residues by (number, insertion code), conformers by
-// (name, alt-loc), searched from the back), without per-line strings: fields are views into the
-// text, and consecutive atoms of one conformer - nearly all of them - skip the searches.
-Structure Structure::from_pdb_text(const std::string &text)
-{
-    Structure s;
-    bool in_first_model = true, seen_model = false;
-    std::size_t counter = 0;
+// The model add_atom builds (chains by id, residues by (number, insertion code), conformers by
+// (name, alt-loc), existing entries searched from the back), from views into the text: no
+// per-line strings, and consecutive atoms of one conformer - nearly all of them - skip the searches.
+struct ModelBuilder {
+    Structure &s;
     size_t ci = (size_t)-1, ri = (size_t)-1, fi = (size_t)-1;  // chain / residue / conformer of the previous atom
-    const char *cur = text.data(), *const end = text.data() + text.size();
-    while (cur < end) {
-        const char *nl = (const char *)std::memchr(cur, '\n', (size_t)(end - cur));
-        const char *stop = nl ? nl : end;
-        LineView line{cur, (size_t)(stop - cur)};
-        cur = nl ? nl + 1 : end;
-        if (line.n && line.p[line.n - 1] == '\r') line.n--;
-        if (line.starts_with("MODEL")) {
-            if (seen_model) in_first_model = false;
-            seen_model = true;
-            continue;
-        }
-        if (line.starts_with("ENDMDL")) { in_first_model = false; continue; }
-        const bool is_atom = line.starts_with("ATOM  "), is_het = line.starts_with("HETATM");
-        if (!(is_atom || is_het) || !in_first_model) continue;
-        if (line.n < 54) { s.warnings.push_back("short ATOM record skipped"); continue; }
-        counter++;
-        const auto name = field_view(line, 13, 16), alt = field_view(line, 17, 17), res_name = field_view(line, 18, 20),
-                   chain_id = field_view(line, 22, 22), icode = field_view(line, 27, 27), element = field_view(line, 77, 78);
-        const std::int64_t res_seq = column_int(line, 23, 26, nullptr);
-        // chain
+
+    // a new, default-constructed record at the end of the atom's conformer
+    AtomRecord &add(const TextView &chain_id, std::int64_t res_seq, const TextView &icode, const TextView &res_name,
+                    const TextView &alt)
+    {
         if (ci == (size_t)-1 || !same(s.chains[ci].id, chain_id)) {
             ci = (size_t)-1;
             for (size_t k = s.chains.size(); k-- > 0;)
@@ -390,7 +314,6 @@ Structure Structure::from_pdb_text(const std::string &text)
             ri = fi = (size_t)-1;
         }
         Chain &chain = s.chains[ci];
-        // residue
         if (ri == (size_t)-1 || chain.residues[ri].serial_number != res_seq || !same(chain.residues[ri].insertion_code, icode)) {
             ri = (size_t)-1;
             for (size_t k = chain.residues.size(); k-- > 0;)
@@ -402,7 +325,6 @@ Structure Structure::from_pdb_text(const std::string &text)
             fi = (size_t)-1;
         }
         Residue &res = chain.residues[ri];
-        // conformer
         if (fi == (size_t)-1 || !same(res.conformers[fi].name, res_name) || !same(res.conformers[fi].alt_loc, alt)) {
             fi = (size_t)-1;
             for (size_t k = 0; k < res.conformers.size(); k++)
@@ -415,7 +337,52 @@ Structure Structure::from_pdb_text(const std::string &text)
         std::vector<AtomRecord> &atoms = res.conformers[fi].atoms;
         if (atoms.capacity() == atoms.size()) atoms.reserve(std::max<size_t>(16, 2 * atoms.size()));
         atoms.emplace_back();
-        AtomRecord &rec = atoms.back();
+        return atoms.back();
+    }
+};
+
+inline void set_element(AtomRecord &rec, const TextView &symbol)
+{
+    rec.element.assign(symbol.first, symbol.second);
+    for (auto &c : rec.element) c = (char)std::toupper((unsigned char)c);
+    if (rec.element.empty()) rec.element = element_from_name(rec.name);
+}
+
+// the next line of `text` from `cur` (advanced past it), without its line end
+inline LineView next_line(const char *&cur, const char *end)
+{
+    const char *nl = (const char *)std::memchr(cur, '\n', (size_t)(end - cur));
+    const char *stop = nl ? nl : end;
+    LineView line{cur, (size_t)(stop - cur)};
+    cur = nl ? nl + 1 : end;
+    if (line.n && line.p[line.n - 1] == '\r') line.n--;
+    return line;
+}
+
+}  // namespace
+
+Structure Structure::from_pdb_text(const std::string &text)
+{
+    Structure s;
+    ModelBuilder model{s};
+    bool in_first_model = true, seen_model = false;
+    std::size_t counter = 0;
+    const char *cur = text.data(), *const end = text.data() + text.size();
+    while (cur < end) {
+        const LineView line = next_line(cur, end);
+        if (line.starts_with("MODEL")) {
+            if (seen_model) in_first_model = false;
+            seen_model = true;
+            continue;
+        }
+        if (line.starts_with("ENDMDL")) { in_first_model = false; continue; }
+        const bool is_atom = line.starts_with("ATOM  "), is_het = line.starts_with("HETATM");
+        if (!(is_atom || is_het) || !in_first_model) continue;
+        if (line.n < 54) { s.warnings.push_back("short ATOM record skipped"); continue; }
+        counter++;
+        const TextView name = field_view(line, 13, 16);
+        AtomRecord &rec = model.add(field_view(line, 22, 22), column_int(line, 23, 26, nullptr), field_view(line, 27, 27),
+                                    field_view(line, 18, 20), field_view(line, 17, 17));
         rec.hetero = is_het;
         bool serial_ok = false;
         const long sv = column_int(line, 7, 11, &serial_ok);
@@ -426,19 +393,64 @@ Structure Structure::from_pdb_text(const std::string &text)
         rec.z = column_decimal(line, 47, 54, 0.0);
         rec.occupancy = column_decimal(line, 55, 60, 1.0);
         rec.b_factor = column_decimal(line, 61, 66, 0.0);
-        rec.element.assign(element.first, element.second);
-        for (auto &c : rec.element) c = (char)std::toupper((unsigned char)c);
-        if (rec.element.empty()) rec.element = element_from_name(rec.name);
+        set_element(rec, field_view(line, 77, 78));
     }
     return s;
 }
 
+namespace {
+
+// mmCIF tokens of one row as views: white-space separated, '...' and "..." quoting (a quote ends
+// at the quote character that is followed by white space or the end of the line).
+inline void tokenize_views(const LineView &line, std::vector<TextView> &out)
+{
+    out.clear();
+    auto space = [](char c) { return c == ' ' || (c >= '\t' && c <= '\r'); };
+    size_t i = 0;
+    const size_t n = line.n;
+    const char *p = line.p;
+    while (i < n) {
+        while (i < n && space(p[i])) i++;
+        if (i >= n) break;
+        if (p[i] == '\'' || p[i] == '"') {
+            const char q = p[i++];
+            size_t j = i;
+            while (j < n && !(p[j] == q && (j + 1 == n || space(p[j + 1])))) j++;
+            out.push_back({p + i, j - i});
+            i = j + 1;
+        } else {
+            size_t j = i;
+            while (j < n && !space(p[j])) j++;
+            out.push_back({p + i, j - i});
+            i = j;
+        }
+    }
+}
+
+// strtol / strtoul on a token: optional sign, then digits up to the first other character
+inline long token_long(const TextView &t)
+{
+    const char *p = t.first, *e = t.first + t.second;
+    bool neg = false;
+    if (p < e && (*p == '-' || *p == '+')) neg = (*p++ == '-');
+    unsigned long v = 0;
+    bool over = false;
+    for (; p < e && *p >= '0' && *p <= '9'; p++) {
+        if (v > (~0ul - 9) / 10) over = true;
+        v = v * 10 + (unsigned long)(*p - '0');
+    }
+    if (over || v > (unsigned long)LONG_MAX) return neg ? LONG_MIN : LONG_MAX;  // strtol saturates
+    return neg ? -(long)v : (long)v;
+}
+
+}  // namespace
+
 Structure Structure::from_mmcif_text(const std::string &text)
 {
     Structure s;
-    std::istringstream is(text);
-    std::string line;
-    std::vector<std::string> cols, tok;
+    ModelBuilder model{s};
+    std::vector<std::string> cols;
+    std::vector<TextView> tok;
     bool in_loop = false, in_atom_site = false;
     std::string first_model;
     auto col = [&](const char *name) -> int {
@@ -450,20 +462,23 @@ Structure Structure::from_mmcif_text(const std::string &text)
         c_aasym = -1, c_lseq = -1, c_aseq = -1, c_ins = -1, c_x = -1, c_y = -1, c_z = -1, c_occ = -1,
         c_b = -1, c_model = -1;
     bool resolved = false;
-    auto val = [&](int c) -> std::string {
-        if (c < 0 || c >= (int)tok.size()) return "";
-        return (tok[c] == "." || tok[c] == "?") ? "" : tok[c];
+    auto val = [&](int c) -> TextView {  // "." and "?" stand for no value
+        if (c < 0 || c >= (int)tok.size()) return {"", 0};
+        const TextView &t = tok[c];
+        return (t.second == 1 && (t.first[0] == '.' || t.first[0] == '?')) ? TextView{t.first, 0} : t;
     };
-    while (std::getline(is, line)) {
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        const std::string t = trim(line);
-        if (t.empty()) continue;
-        if (t == "loop_") { in_loop = true; in_atom_site = false; cols.clear(); resolved = false; continue; }
+    const char *cur = text.data(), *const end = text.data() + text.size();
+    while (cur < end) {
+        const LineView raw = next_line(cur, end);
+        const TextView tv = field_view(raw, 1, raw.n);  // trimmed
+        if (tv.second == 0) continue;
+        const LineView t{tv.first, tv.second};
+        if (t.n == 5 && t.starts_with("loop_")) { in_loop = true; in_atom_site = false; cols.clear(); resolved = false; continue; }
         if (t[0] == '#') { in_loop = false; in_atom_site = false; continue; }
         if (in_loop && t[0] == '_') {
-            if (t.rfind("_atom_site.", 0) == 0) {
+            if (t.starts_with("_atom_site.")) {
                 in_atom_site = true;
-                std::string name = t.substr(11);
+                std::string name(t.p + 11, t.n - 11);
                 name = trim(name.substr(0, name.find_first_of(" \t")));
                 cols.push_back(name);
             } else {
@@ -472,7 +487,7 @@ Structure Structure::from_mmcif_text(const std::string &text)
             continue;
         }
         if (!(in_loop && in_atom_site)) continue;
-        if (t[0] == '_' ) { in_loop = false; continue; }
+        if (t[0] == '_') { in_loop = false; continue; }
         if (!resolved) {
             c_group = col("group_PDB"); c_id = col("id"); c_sym = col("type_symbol");
             c_atom = col("label_atom_id"); c_alt = col("label_alt_id"); c_comp = col("label_comp_id");
@@ -484,33 +499,28 @@ Structure Structure::from_mmcif_text(const std::string &text)
             if (c_x < 0 || c_y < 0 || c_z < 0 || c_atom < 0 || c_comp < 0)
                 throw std::runtime_error("mmCIF _atom_site loop lacks required columns");
         }
-        tokenize(t, tok);
+        tokenize_views(t, tok);
         if (tok.size() < cols.size()) { s.warnings.push_back("short _atom_site row skipped"); continue; }
-        const std::string model = val(c_model);
-        if (first_model.empty()) first_model = model.empty() ? "1" : model;
-        if (!model.empty() && model != first_model) continue;
-        FlatAtom a;
-        a.rec.hetero = val(c_group) == "HETATM";
-        a.rec.serial = (std::size_t)std::strtoul(val(c_id).c_str(), nullptr, 10);
-        a.rec.name = val(c_atom);
-        a.alt = val(c_alt);
-        a.res_name = val(c_comp);
-        a.chain = c_aasym >= 0 && !val(c_aasym).empty() ? val(c_aasym) : val(c_lasym);
-        const std::string seq = c_aseq >= 0 && !val(c_aseq).empty() ? val(c_aseq) : val(c_lseq);
-        a.res_seq = std::strtol(seq.c_str(), nullptr, 10);
-        a.icode = val(c_ins);
+        const TextView model_id = val(c_model);
+        if (first_model.empty()) first_model = model_id.second ? std::string(model_id.first, model_id.second) : "1";
+        if (model_id.second && !same(first_model, model_id)) continue;
+        const TextView chain_id = c_aasym >= 0 && val(c_aasym).second ? val(c_aasym) : val(c_lasym);
+        const TextView seq = c_aseq >= 0 && val(c_aseq).second ? val(c_aseq) : val(c_lseq);
+        const TextView name = val(c_atom), group = val(c_group);
+        AtomRecord &rec = model.add(chain_id, token_long(seq), val(c_ins), val(c_comp), val(c_alt));
+        rec.hetero = group.second == 6 && std::memcmp(group.first, "HETATM", 6) == 0;
+        rec.serial = (std::size_t)token_long(val(c_id));
+        rec.name.assign(name.first, name.second);
         auto num = [&](int c, double missing) {
-            if (c < 0 || c >= (int)tok.size() || tok[c] == "." || tok[c] == "?") return missing;
-            return parse_decimal(tok[c].data(), tok[c].size());
+            const TextView v = val(c);
+            return v.second ? parse_decimal(v.first, v.second) : missing;
         };
-        a.rec.x = num(c_x, 0.0);
-        a.rec.y = num(c_y, 0.0);
-        a.rec.z = num(c_z, 0.0);
-        a.rec.occupancy = num(c_occ, 1.0);
-        a.rec.b_factor = num(c_b, 0.0);
-        a.rec.element = upper(val(c_sym));
-        if (a.rec.element.empty()) a.rec.element = element_from_name(a.rec.name);
-        add_atom(s, a);
+        rec.x = num(c_x, 0.0);
+        rec.y = num(c_y, 0.0);
+        rec.z = num(c_z, 0.0);
+        rec.occupancy = num(c_occ, 1.0);
+        rec.b_factor = num(c_b, 0.0);
+        set_element(rec, val(c_sym));
     }
     return s;
 }
