@@ -643,6 +643,35 @@ def test_largest_structure_binned_in_lds_and_smallest_that_is_not(n_atoms):
     assert np.array_equal(atom, want)
 
 
+def test_two_contexts_with_batches_in_flight_at_the_same_time():
+    """Two contexts (own workspaces) on two streams, batch k + 1 enqueued before batch k is waited
+    for: the kernels of both share the GPU; every batch equals the oracle."""
+    import torch
+    import rustsasa_amd
+    dev = torch.device("cuda:0")
+    batches = [bw.synthetic_proteome(60, seed=500 + k) for k in range(4)]
+    wants = [po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=8)
+             for b in batches]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    dv = [(t(b.x), t(b.y), t(b.z), t(b.radius), t(b.ids.view(np.int64))) for b in batches]
+    outs = [torch.full((b.n_atoms,), -1.0, dtype=torch.float32, device=dev) for b in batches]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    with rustsasa_amd.Context(0) as c0, rustsasa_amd.Context(0) as c1:
+        ctxs = [c0, c1]
+        for rep in range(3):
+            for k, b in enumerate(batches):
+                if k >= 2:
+                    ctxs[k % 2].wait()
+                x, y, z, r, ids = dv[k]
+                ctxs[k % 2].enqueue_device(x, y, z, r, ids, b.structure_offsets, outs[k], None, None, None, PROBE, 100,
+                                           stream=streams[k % 2].cuda_stream)
+            c0.wait()
+            c1.wait()
+            for k in range(4):
+                assert np.array_equal(outs[k].cpu().numpy(), wants[k]), (rep, k)
+
+
 def test_many_tiny_structures(ctx):
     """70 000 structures of 1-3 atoms: the grid placement scan runs over several chunks of
     per-workgroup sums, every structure is its own LDS-binned grid."""
