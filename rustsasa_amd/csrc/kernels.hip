@@ -99,7 +99,13 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
     for (int k = 0; k < 3; k++)                                    // spatial_grid.rs:39-43
         d[k] = f2u_sat(ceilf((mx[k] - mn[k]) * inv)) + 1u;
     unsigned long long nc = (unsigned long long)d[0] * d[1] * d[2];
-    if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000))) { bad = true; nc = 1; d[0] = d[1] = d[2] = 1; }
+    if (a.n_atoms == 0) {
+        // an empty structure has no atoms to place or to look up: one cell, whatever the probe radius
+        // (probe 0 would make its cell size 0 - not an error of the batch)
+        nc = 1; d[0] = d[1] = d[2] = 1;
+        mn[0] = mn[1] = mn[2] = 0.0f;
+        inv = 1.0f; cell = 1.0f;
+    } else if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000))) { bad = true; nc = 1; d[0] = d[1] = d[2] = 1; }
     if (nc > 0x7FFFFFFFull) { too_large = true; nc = 1; d[0] = d[1] = d[2] = 1; }
     g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
     g.inv_cell = inv;

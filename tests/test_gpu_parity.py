@@ -672,6 +672,19 @@ def test_two_contexts_with_batches_in_flight_at_the_same_time():
                 assert np.array_equal(outs[k].cpu().numpy(), wants[k]), (rep, k)
 
 
+def test_empty_structure_in_a_batch_with_zero_probe(ctx):
+    """probe + max radius of an EMPTY structure is 0 when the probe is 0: not an invalid batch."""
+    rng = np.random.default_rng(3)
+    xyz = rng.uniform(0, 20, (300, 3)).astype(np.float32)
+    r = rng.uniform(1.2, 2.0, 300).astype(np.float32)
+    so = np.array([0, 0, 120, 120, 300, 300], np.uint32)
+    x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
+    for probe in (0.0, 1.4):
+        got, _ = ctx.calculate_sasa_batch(x, y, z, r, None, so, probe, 100)
+        want = po.calculate_sasa_batch(x, y, z, r, None, so, probe, 100, 8)
+        assert np.array_equal(got, want)
+
+
 def test_many_tiny_structures(ctx):
     """70 000 structures of 1-3 atoms: the grid placement scan runs over several chunks of
     per-workgroup sums, every structure is its own LDS-binned grid."""

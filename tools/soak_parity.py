@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU: batches of structures with random sizes, shapes (compact, elongated,
+sparse, dense clusters, coincident atoms), radii, ids (some duplicated) and point counts, every atom compared
+with the oracle.  usage: tools/soak_parity.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401  (one HIP runtime per process)
+import rustsasa_amd
+from oracle import pyoracle as po
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+
+
+def structure(rng):
+    kind = rng.integers(6)
+    n = int(rng.choice([1, 2, 7, 60, 300, 1500, 4000, 9000, 20000, 70000], p=[.03, .03, .04, .1, .2, .3, .15, .1, .04, .01]))
+    if kind == 0:    # compact blob at protein density
+        side = (n / 0.05) ** (1 / 3)
+        xyz = rng.uniform(0, side, (n, 3))
+    elif kind == 1:  # elongated
+        xyz = rng.uniform(0, 1, (n, 3)) * np.array([rng.uniform(200, 4000), rng.uniform(10, 60), rng.uniform(10, 60)])
+    elif kind == 2:  # sparse: many windows of cells
+        xyz = rng.uniform(0, 1, (n, 3)) * rng.uniform(300, 1500, 3)
+    elif kind == 3:  # dense cluster(s): many atoms per cell
+        centers = rng.uniform(0, 60, (max(1, n // 400), 3))
+        xyz = centers[rng.integers(len(centers), size=n)] + rng.normal(scale=rng.uniform(0.3, 2.0), size=(n, 3))
+    elif kind == 4:  # lattice with coincident points
+        xyz = np.round(rng.uniform(0, 40, (n, 3)) / 2.0) * 2.0
+    else:            # plane
+        xyz = rng.uniform(0, 1, (n, 3)) * np.array([120.0, 120.0, 0.5])
+    xyz += rng.uniform(-500, 500, 3)
+    r = rng.uniform(1.0, 2.2, n) if rng.random() < 0.8 else np.full(n, rng.uniform(1.2, 2.0))
+    return xyz.astype(np.float32), r.astype(np.float32)
+
+
+t_end = time.time() + budget
+it = atoms = 0
+with rustsasa_amd.Context(0) as ctx:
+    while time.time() < t_end:
+        parts = [structure(rng) for _ in range(int(rng.integers(1, 40)))]
+        if rng.random() < 0.2:
+            parts.insert(int(rng.integers(len(parts) + 1)), (np.zeros((0, 3), np.float32), np.zeros(0, np.float32)))
+        xyz = np.concatenate([p[0] for p in parts]); r = np.concatenate([p[1] for p in parts])
+        so = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.uint32)
+        ids = np.arange(len(xyz), dtype=np.uint64)
+        if rng.random() < 0.3 and len(ids) > 4:  # some duplicated ids
+            k = rng.integers(len(ids), size=max(1, len(ids) // 50)); ids[k] = ids[(k + 1) % len(ids)]
+        use_ids = ids if rng.random() < 0.8 else None
+        n_points = int(rng.choice([1, 20, 64, 100, 100, 100, 128, 200, 960, 1000]))
+        probe = float(rng.choice([1.4, 1.4, 0.0, 0.7, 2.5]))
+        x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
+        got, _ = ctx.calculate_sasa_batch(x, y, z, r, use_ids, so, probe, n_points)
+        want = po.calculate_sasa_batch(x, y, z, r, use_ids, so, probe, n_points, 8, threads=0)
+        if not np.array_equal(got, want):
+            bad = np.flatnonzero(got != want)
+            np.savez("soak_failure.npz", xyz=xyz, r=r, so=so, ids=ids, n_points=n_points, probe=probe)
+            print(f"MISMATCH iteration {it}: {len(bad)} of {len(got)} atoms differ (first {bad[:5]}), saved soak_failure.npz")
+            sys.exit(1)
+        it += 1; atoms += len(got)
+print(f"soak ok: {it} batches, {atoms} atoms, all equal to the oracle")
