@@ -52,8 +52,43 @@ with rustsasa_amd.Context(0) as ctx:
         n_points = int(rng.choice([1, 20, 64, 100, 100, 100, 128, 200, 960, 1000]))
         probe = float(rng.choice([1.4, 1.4, 0.0, 0.7, 2.5]))
         x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
-        got, _ = ctx.calculate_sasa_batch(x, y, z, r, use_ids, so, probe, n_points)
+        # random residues: consecutive runs of atoms that never cross a structure boundary
+        cuts = set(so.tolist())
+        if len(xyz):
+            cuts.update(rng.integers(0, len(xyz), size=max(1, len(xyz) // 9)).tolist())
+        ro = np.array(sorted(cuts), np.uint32)
+        mode = rng.integers(3)
+        if mode == 0:    # host arrays in, host arrays out
+            got, got_res = ctx.calculate_sasa_batch(x, y, z, r, use_ids, so, probe, n_points, residue_offsets=ro)
+            got_k = None
+        else:            # device-resident, with the per-atom candidate counts
+            dev = torch.device("cuda:0")
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+            out = torch.full((len(xyz),), -1.0, dtype=torch.float32, device=dev)
+            res = torch.full((len(ro) - 1,), -1.0, dtype=torch.float32, device=dev)
+            kk = torch.zeros(len(xyz), dtype=torch.int32, device=dev)
+            ctx.enqueue_device(tt(x), tt(y), tt(z), tt(r), None if use_ids is None else tt(use_ids.view(np.int64)), so, out,
+                               tt(ro.view(np.int32)), res, kk, probe, n_points, stream=torch.cuda.current_stream().cuda_stream)
+            ctx.wait()
+            got, got_res, got_k = out.cpu().numpy(), res.cpu().numpy(), kk.cpu().numpy().view(np.uint32)
         want = po.calculate_sasa_batch(x, y, z, r, use_ids, so, probe, n_points, 8, threads=0)
+        want_res = np.array([np.float32(0) if a == b else np.add.reduce(want[a:b], dtype=np.float32) for a, b in zip(ro[:-1], ro[1:])],
+                            np.float32) if len(ro) > 1 else np.zeros(0, np.float32)
+        # sequential f32 sums (options.rs:209-216): numpy's pairwise reduce differs for long runs, so compare run by run
+        for k_, (a, b) in enumerate(zip(ro[:-1], ro[1:])):
+            acc = np.float32(0)
+            for v in want[a:b]:
+                acc = np.float32(acc + v)
+            want_res[k_] = acc
+        if got_k is not None and len(xyz) <= 30000:
+            for s0, s1 in zip(so[:-1], so[1:]):
+                if s1 > s0:
+                    _, _, wk = po.calculate_sasa_internal(x[s0:s1], y[s0:s1], z[s0:s1], r[s0:s1], None if use_ids is None else use_ids[s0:s1],
+                                                          probe, n_points, 8, return_details=True)
+                    if not np.array_equal(got_k[s0:s1], wk):
+                        print(f"K MISMATCH iteration {it}"); sys.exit(1)
+        if not np.array_equal(got_res, want_res):
+            print(f"RESIDUE MISMATCH iteration {it}: {int((got_res != want_res).sum())} of {len(want_res)}"); sys.exit(1)
         if not np.array_equal(got, want):
             bad = np.flatnonzero(got != want)
             np.savez("soak_failure.npz", xyz=xyz, r=r, so=so, ids=ids, n_points=n_points, probe=probe)
