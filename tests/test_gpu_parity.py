@@ -335,10 +335,12 @@ def test_uniform_1m_atoms_960_points_full_size(ctx):
     assert np.array_equal(k, want_k)
 
 
-@pytest.mark.parametrize("n_points", [1000, 1100])
+@pytest.mark.parametrize("n_points", [200, 1000, 1100, 1344, 1348, 1352, 2000])
 def test_uniform_box_many_points_with_remainder(ctx, n_points):
-    """More than 128 points with a remainder (1100 = 137 * 8 + 4) on a structure large enough for
-    the tail binning route."""
+    """More than 128 points, with and without a remainder (1100 = 137 * 8 + 4), on a structure large
+    enough for the batch-wide binning route and the matrix-core kernel: 4-, 8- and 12-wave workgroups
+    (200 / 1000 / 1344 points), the largest count the kernel takes (1344), the first ones it leaves
+    to the general kernel."""
     b = bw.synthetic_uniform(70_000, seed=9)
     atom, _, _ = _device_run(ctx, b, n_points=n_points, want_k=False, want_res=False)
     want = po.calculate_sasa_internal(b.x, b.y, b.z, b.radius, b.ids, PROBE, n_points, 8, threads=0)
