@@ -687,6 +687,57 @@ def test_empty_structure_in_a_batch_with_zero_probe(ctx):
         assert np.array_equal(got, want)
 
 
+def test_host_threads_share_one_context_and_use_their_own():
+    """What rayon workers would do through the Rust shim: threads calling concurrently, (a) every
+    thread with its own context, (b) all on ONE context (calls are serialised inside).  Different
+    inputs and point counts per thread; every result equals the oracle; errors of one thread stay its own."""
+    import threading
+    import rustsasa_amd
+    rng = np.random.default_rng(77)
+    jobs = []
+    for t in range(8):
+        n = int(rng.integers(200, 3000))
+        xyz = rng.uniform(0, (n / 0.05) ** (1 / 3), (n, 3)).astype(np.float32)
+        r = rng.uniform(1.2, 2.0, n).astype(np.float32)
+        pts = int(rng.choice([20, 100, 200, 960]))
+        x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
+        jobs.append((x, y, z, r, pts, po.calculate_sasa_internal(x, y, z, r, None, PROBE, pts, 8)))
+
+    def run(make_ctx, shared=None):
+        errors = []
+
+        def work(t):
+            try:
+                c = shared if shared is not None else make_ctx()
+                x, y, z, r, pts, want = jobs[t]
+                for rep in range(20):
+                    got = c.calculate_sasa_soa(x, y, z, r, None, PROBE, pts)
+                    if not np.array_equal(got, want):
+                        errors.append((t, rep, "mismatch"))
+                    if rep == 7:  # an invalid call in the middle: the error belongs to this thread
+                        try:
+                            c.calculate_sasa_soa(x, y, z, r, None, float("nan"), pts)
+                            errors.append((t, rep, "no error"))
+                        except rustsasa_amd.RsasaError as e:
+                            if "probe_radius" not in str(e):
+                                errors.append((t, rep, str(e)))
+                if shared is None:
+                    c.close()
+            except Exception as e:  # noqa: BLE001
+                errors.append((t, -1, repr(e)))
+
+        ts = [threading.Thread(target=work, args=(t,)) for t in range(len(jobs))]
+        for th in ts:
+            th.start()
+        for th in ts:
+            th.join()
+        assert not errors, errors[:5]
+
+    run(lambda: rustsasa_amd.Context(0))
+    with rustsasa_amd.Context(0) as one:
+        run(None, shared=one)
+
+
 def test_many_tiny_structures(ctx):
     """70 000 structures of 1-3 atoms: the grid placement scan runs over several chunks of
     per-workgroup sums, every structure is its own LDS-binned grid."""
