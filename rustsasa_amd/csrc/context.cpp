@@ -697,6 +697,7 @@ bool small_grid(const float mn_in[3], const float mx_in[3], float max_r, float p
 }
 
 constexpr size_t kSmallAtoms = 32768, kSmallStructures = 256;
+constexpr size_t kSingleAtoms = 8192;  // one structure up to this size: its atoms are read from pinned host memory
 constexpr int kNotSmall = 1;  // (positive: not an error) the batch goes through the general path
 
 // Batches of a few structures handed over in host memory - the literal drop-in use, one
@@ -791,13 +792,18 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if (R) std::memcpy(h + o_res, ro, (R + 1) * 4);
     hipStream_t st = ctx->stream;
     char *d = (char *)ctx->small_in.p, *dout = (char *)ctx->small_out.p;
-    RS_HIP(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    // One structure of a few thousand atoms - the per-structure call: no upload at all.  The binning
+    // kernel gets grid and status as kernel arguments and reads the atoms from the pinned staging
+    // block (they cross the link once or twice; an upload costs 15 us before the first kernel starts).
+    const bool single = S == 1 && N <= kSingleAtoms;
+    if (!single) RS_HIP(ctx, hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, st));
+    const char *src = single ? h : d;
 
     BatchView v{};
-    v.x = (const float *)(d + o_x); v.y = (const float *)(d + o_y); v.z = (const float *)(d + o_z);
-    v.radius = (const float *)(d + o_r);
-    v.id = id ? (const uint64_t *)(d + o_id) : nullptr;
-    v.residue_offsets = R ? (const uint32_t *)(d + o_res) : nullptr;
+    v.x = (const float *)(src + o_x); v.y = (const float *)(src + o_y); v.z = (const float *)(src + o_z);
+    v.radius = (const float *)(src + o_r);
+    v.id = id ? (const uint64_t *)(src + o_id) : nullptr;
+    v.residue_offsets = R ? (const uint32_t *)(src + o_res) : nullptr;
     v.n_atoms = (uint32_t)N; v.n_structures = (uint32_t)S; v.n_residues = (uint32_t)R;
     v.probe = probe;
     v.grids = (StructGrid *)(d + o_grid);
@@ -816,7 +822,8 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     v.sorted_id32 = id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
     v.atom_sasa = (float *)(dout + o_oa);
     v.residue_sasa = R ? (float *)(dout + o_or) : nullptr;
-    launch_sort_lds(v, st);
+    if (single) launch_sort_single(v, SingleJob{grids[0], stt}, st);
+    else launch_sort_lds(v, st);
     launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
     launch_residue_sums(v, st);
     char *hout = h + in_bytes;

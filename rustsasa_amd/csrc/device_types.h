@@ -105,6 +105,13 @@ struct BatchView {
     uint32_t *neighbor_counts;    // may be null
 };
 
+// Grid and status of a one-structure batch, computed by the host and handed to k_sort_window<true> as
+// kernel arguments.
+struct SingleJob {
+    StructGrid grid;
+    BatchStatus status;
+};
+
 // Occlusion kernel selection (RSASA_OCCLUSION_KERNEL / RSASA_ATOMS_PER_WAVE, read once per
 // context; for A/B measurements -- every version computes identical results).
 struct OcclusionTuning {
@@ -119,6 +126,7 @@ struct OcclusionTuning {
 // Launchers implemented in kernels.hip / occlusion.hip.  Each only enqueues on `stream`.
 void launch_grid_prepare(const BatchView &b, hipStream_t stream);
 void launch_sort_lds(const BatchView &b, hipStream_t stream);
+void launch_sort_single(const BatchView &b, const SingleJob &job, hipStream_t stream);
 void launch_sort_tail(const BatchView &b, hipStream_t stream);
 // Which atoms (cell-sorted positions) an occlusion launch covers: the tail's binning may still be
 // running on another stream while the LDS-binned structures are processed.

@@ -261,7 +261,13 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
 // beyond the registers' share (structures with more than kSlots * 1024 atoms) keep their position
 // in memory (rank_of); positions beyond the staging area (a window with more atoms than it
 // holds) are stored directly.
-__global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b)
+//
+// SINGLE: a batch of ONE structure whose grid and status the host has already computed (the
+// per-structure call, context.cpp run_small_host_batch).  They arrive as kernel arguments - no upload
+// precedes the launch, the inputs are read from pinned host memory - and the first workgroup stores
+// them where the later kernels look for them.
+template <bool SINGLE>
+__global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b, SingleJob single)
 {
     constexpr int kSlots = 8;                              // atoms per thread with (cell, position) in registers
     constexpr int kChunk = 4;                              // slots whose loads are in flight together
@@ -269,10 +275,23 @@ __global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindowCells / 2 + 4];
     __shared__ uint32_t smem32[16];
     __shared__ uint32_t s_below;
-    if (batch_aborted(b.status) || blockIdx.x >= b.status->n_windows) return;
-    const uint2 job = b.windows[blockIdx.x];
-    const uint32_t s = job.x, c0 = job.y * kWindowCells;
-    const StructGrid g = b.grids[s];
+    uint32_t s, c0;
+    StructGrid g;
+    if (SINGLE) {
+        s = 0;
+        c0 = blockIdx.x * kWindowCells;  // (one workgroup per window was launched)
+        g = single.grid;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            b.grids[0] = g;
+            *b.status = single.status;
+        }
+    } else {
+        if (batch_aborted(b.status) || blockIdx.x >= b.status->n_windows) return;
+        const uint2 job = b.windows[blockIdx.x];
+        s = job.x;
+        c0 = job.y * kWindowCells;
+        g = b.grids[s];
+    }
     const uint32_t tid = threadIdx.x;
     const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
     const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z, *__restrict__ pr = b.radius;
@@ -631,7 +650,14 @@ void launch_grid_prepare(const BatchView &b, hipStream_t stream)
 // the surplus exits.
 void launch_sort_lds(const BatchView &b, hipStream_t stream)
 {
-    if (b.window_capacity) hipLaunchKernelGGL(k_sort_window, dim3(b.window_capacity), dim3(1024), 0, stream, b);
+    if (b.window_capacity) hipLaunchKernelGGL(k_sort_window<false>, dim3(b.window_capacity), dim3(1024), 0, stream, b, SingleJob{});
+}
+
+// One structure, grid and status from the host (see k_sort_window<true>): one workgroup per window.
+void launch_sort_single(const BatchView &b, const SingleJob &job, hipStream_t stream)
+{
+    const uint32_t n_win = grid_windows(job.grid.n_cells);
+    if (n_win) hipLaunchKernelGGL(k_sort_window<true>, dim3(n_win), dim3(1024), 0, stream, b, job);
 }
 
 // Batch-wide binning of the other structures (the tail).  Independent of launch_sort_lds: the
