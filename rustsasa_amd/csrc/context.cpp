@@ -820,14 +820,16 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
     v.sorted_id = id ? (uint64_t *)ctx->sorted_id.p : nullptr;
     v.sorted_id32 = id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
-    v.atom_sasa = (float *)(dout + o_oa);
-    v.residue_sasa = R ? (float *)(dout + o_or) : nullptr;
+    // (the single-structure call also gets its results written straight into the pinned block)
+    char *hout = h + in_bytes;
+    char *outp = single ? hout : dout;
+    v.atom_sasa = (float *)(outp + o_oa);
+    v.residue_sasa = R ? (float *)(outp + o_or) : nullptr;
     if (single) launch_sort_single(v, SingleJob{grids[0], stt}, st);
     else launch_sort_lds(v, st);
     launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
     launch_residue_sums(v, st);
-    char *hout = h + in_bytes;
-    RS_HIP(ctx, hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
+    if (!single) RS_HIP(ctx, hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
     RS_HIP(ctx, hipGetLastError());
     RS_HIP(ctx, hipStreamSynchronize(st));
     if (out_atom) std::memcpy(out_atom, hout + o_oa, N * 4);

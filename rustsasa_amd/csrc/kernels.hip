@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
 // precedes the launch, the inputs are read from pinned host memory - and the first workgroup stores
 // them where the later kernels look for them.
 template <bool SINGLE>
-__global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b, SingleJob single)
+__global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView b, SingleJob single)
 {
     constexpr int kSlots = 8;                              // atoms per thread with (cell, position) in registers
     constexpr int kChunk = 4;                              // slots whose loads are in flight together
@@ -306,6 +306,10 @@ __global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b, SingleJob 
     if (tid == 0) s_below = 0;
     // ---- cells of the structure's first kSlots * 1024 atoms (slot k of a thread: atom a0 + tid + 1024 k) ----
     uint32_t rcell[kSlots], rpos[kSlots];
+    // SINGLE: the whole record stays in registers (the inputs sit in host memory there: one trip over
+    // the link instead of two; a workgroup has the CU to itself and 128 VGPRs)
+    float kx[SINGLE ? kSlots : 1], ky[SINGLE ? kSlots : 1], kz[SINGLE ? kSlots : 1], kr[SINGLE ? kSlots : 1];
+    uint64_t kid[SINGLE ? kSlots : 1];
     uint32_t below = 0;  // atoms in earlier windows (wave-uniform count)
 #pragma unroll
     for (int k0 = 0; k0 < kSlots; k0 += kChunk) {
@@ -313,10 +317,16 @@ __global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b, SingleJob 
 #pragma unroll
         for (int k = 0; k < kChunk; k++) {
             x[k] = y[k] = z[k] = 0.f;
+            if (SINGLE) { kr[k0 + k] = 0.f; kid[k0 + k] = 0ull; }
             if (1024u * (k0 + k) < g.n_atoms) {
                 const uint32_t i = min(a0 + tid + 1024u * (k0 + k), a1 - 1u);
                 x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+                if (SINGLE) {
+                    kr[k0 + k] = pr[i];
+                    if (pid) kid[k0 + k] = pid[i];
+                }
             }
+            if (SINGLE) { kx[k0 + k] = x[k]; ky[k0 + k] = y[k]; kz[k0 + k] = z[k]; }
         }
 #pragma unroll
         for (int k = 0; k < kChunk; k++) {
@@ -430,7 +440,10 @@ __global__ __launch_bounds__(1024, 8) void k_sort_window(BatchView b, SingleJob 
             for (int k = 0; k < kChunk; k++) {
                 v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 id[k] = 0ull;
-                if (rcell[k0 + k] < n_cells) {
+                if (SINGLE) {
+                    v[k] = make_float4(kx[k0 + k], ky[k0 + k], kz[k0 + k], kr[k0 + k]);
+                    id[k] = kid[k0 + k];
+                } else if (rcell[k0 + k] < n_cells) {
                     const uint32_t i = a0 + tid + 1024u * (k0 + k);
                     v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
                     if (pid) id[k] = pid[i];

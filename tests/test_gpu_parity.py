@@ -738,6 +738,39 @@ def test_host_threads_share_one_context_and_use_their_own():
         run(None, shared=one)
 
 
+def test_single_structure_calls_of_random_shapes(ctx):
+    """The per-structure call (one structure, up to 8 192 atoms: no upload, results written to pinned
+    memory by the kernels): random sizes around that limit, shapes, ids, residues and point counts."""
+    rng = np.random.default_rng(4242)
+    for it in range(60):
+        n = int(rng.choice([1, 2, 5, 64, 700, 2600, 8191, 8192, 8193, 12000]))
+        kind = it % 4
+        if kind == 0:
+            xyz = rng.uniform(0, (n / 0.05) ** (1 / 3) + 1.0, (n, 3))
+        elif kind == 1:
+            xyz = rng.uniform(0, 1, (n, 3)) * np.array([rng.uniform(100, 2000), 30.0, 30.0])  # several windows
+        elif kind == 2:
+            n = min(n, 700)
+            xyz = rng.normal(scale=1.5, size=(n, 3))                                           # one dense cluster (every atom a candidate)
+        else:
+            xyz = rng.uniform(0, 1, (n, 3)) * rng.uniform(200, 900, 3)                          # sparse
+        xyz = (xyz + rng.uniform(-300, 300, 3)).astype(np.float32)
+        r = rng.uniform(1.0, 2.1, n).astype(np.float32)
+        ids = np.arange(n, dtype=np.uint64) if it % 3 else None
+        if ids is not None and n > 3 and it % 2:
+            ids[1] = ids[0]
+        pts = int(rng.choice([1, 64, 100, 100, 960]))
+        so = np.array([0, n], np.uint32)
+        ro = np.unique(np.concatenate([[0, n], rng.integers(0, n + 1, size=max(1, n // 8))])).astype(np.uint32)
+        x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
+        got, got_res = ctx.calculate_sasa_batch(x, y, z, r, ids, so, PROBE, pts, residue_offsets=ro)
+        want = po.calculate_sasa_internal(x, y, z, r, ids, PROBE, pts, 8, threads=0)
+        assert np.array_equal(got, want), (it, n, pts)
+        for a, b_, v in zip(ro[:-1], ro[1:], got_res):  # sequential f32 sums (options.rs:209-216)
+            acc = np.cumsum(want[a:b_], dtype=np.float32)[-1] if b_ > a else np.float32(0)
+            assert v == acc, (it, n, a)
+
+
 def test_many_tiny_structures(ctx):
     """70 000 structures of 1-3 atoms: the grid placement scan runs over several chunks of
     per-workgroup sums, every structure is its own LDS-binned grid."""
