@@ -825,6 +825,11 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     char *outp = single ? hout : dout;
     v.atom_sasa = (float *)(outp + o_oa);
     v.residue_sasa = R ? (float *)(outp + o_or) : nullptr;
+    // (and the general kernel is only launched if the straight-line one says it left atoms to it:
+    // a word of the pinned block's header, looked at after the stream has drained)
+    uint32_t *flag = reinterpret_cast<uint32_t *>(h + 56);
+    *flag = 0u;
+    v.defer_flag = single ? flag : nullptr;
     if (single) launch_sort_single(v, SingleJob{grids[0], stt}, st);
     else launch_sort_lds(v, st);
     launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
@@ -832,6 +837,12 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if (!single) RS_HIP(ctx, hipMemcpyAsync(hout, dout, out_bytes, hipMemcpyDeviceToHost, st));
     RS_HIP(ctx, hipGetLastError());
     RS_HIP(ctx, hipStreamSynchronize(st));
+    if (single && *flag) {
+        launch_occlusion_deferred(v, lat, st);
+        launch_residue_sums(v, st);
+        RS_HIP(ctx, hipGetLastError());
+        RS_HIP(ctx, hipStreamSynchronize(st));
+    }
     if (out_atom) std::memcpy(out_atom, hout + o_oa, N * 4);
     if (R) std::memcpy(out_res, hout + o_or, R * 4);
     return RSASA_OK;

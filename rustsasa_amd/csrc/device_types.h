@@ -103,6 +103,10 @@ struct BatchView {
     float *atom_sasa;             // never null (workspace buffer when the caller passed none)
     float *residue_sasa;          // may be null
     uint32_t *neighbor_counts;    // may be null
+    // Nullable, pinned host memory (the one-structure call): k_occlusion_fast sets it to 1 when it leaves an
+    // atom to the general kernel, and launch_occlusion then does NOT launch that kernel - the caller looks at
+    // the flag after the stream has drained and calls launch_occlusion_deferred if it is set (it rarely is).
+    uint32_t *defer_flag;
 };
 
 // Grid and status of a one-structure batch, computed by the host and handed to k_sort_window<true> as
@@ -137,6 +141,8 @@ enum OcclusionPart : uint32_t {
 };
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
                       OcclusionPart part, hipStream_t stream);
+// The general kernel over the atoms the straight-line kernel deferred (see BatchView::defer_flag).
+void launch_occlusion_deferred(const BatchView &b, const Lattice &lat, hipStream_t stream);
 void launch_residue_sums(const BatchView &b, hipStream_t stream);
 void launch_expand_frames(const float *xyz, const float *radius, const uint64_t *id,
                           const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t res_stride,

@@ -136,6 +136,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         // straight-line kernel for every atom it can take; the rest go through the general kernel
         a3.work_list_out = b.deferred_list;
         a3.work_count_out = &b.status->deferred;
+        a3.defer_flag = mx ? nullptr : b.defer_flag;  // (only k_occlusion_fast reports through the flag)
         const bool rem = lat.n_points != lat.n_fused;
         const bool half1 = lat.n_fused <= 96u;  // the second chunk's fused points fit half a wave
         a3.part = part;
@@ -166,6 +167,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }
         if (part == kOccHead) return;  // the general kernel follows the last fast launch
+        if (a3.defer_flag) return;     // the caller launches it if the flag says so
         a3.work_list = b.deferred_list;
         a3.work_count = &b.status->deferred;
         a3.atoms_per_wave = 1;
@@ -182,6 +184,19 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     } else {
         hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
     }
+}
+
+void launch_occlusion_deferred(const BatchView &b, const Lattice &lat, hipStream_t stream)
+{
+    if (!b.n_atoms) return;
+    OccArgs a{b, lat, 0, 1, 0};
+    OccArgs3 a3 = make_args3(a);
+    a3.work_list = b.deferred_list;
+    a3.work_count = &b.status->deferred;
+    a3.atoms_per_wave = 1;
+    const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), 1024u);
+    if (b.id) hipLaunchKernelGGL((k_occlusion_v3<2, true, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
+    else hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
 }
 
 }  // namespace rsasa
