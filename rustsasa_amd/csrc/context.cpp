@@ -246,6 +246,23 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
 }
 
 // Enqueues the whole pipeline for the batch `pd` on its stream, using host slot `hs`.
+// The streams beside the launch stream are created on first use.  The runtime multiplexes a
+// process's streams onto a few hardware queues in creation order: a context that only serves
+// per-structure calls should hold ONE stream, or the launch streams of several contexts (one per host
+// thread) all land on the same queue and their kernels run one after the other.
+int ensure_side_stream(rsasa_context *ctx)
+{
+    if (!ctx->side_stream) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    return RSASA_OK;
+}
+
+int ensure_copy_streams(rsasa_context *ctx)
+{
+    if (!ctx->copy_stream) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->d2h_stream) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    return RSASA_OK;
+}
+
 int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot &hs)
 {
     const rsasa_device_batch_t &bt = pd.batch;
@@ -351,6 +368,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     launch_grid_prepare(v, st);
     const bool overlap = ctx->overlap_tail && has_tail;
+    if (overlap && (rc = ensure_side_stream(ctx))) return rc;
     if (overlap) {
         launch_sort_lds(v, st);
         // fork here, not before the LDS binning: two bandwidth-bound phases gain nothing from
@@ -492,11 +510,8 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     hipError_t e = guard.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) {
@@ -888,6 +903,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if (rc != kNotSmall) return rc;
     }
 
+    if ((rc = ensure_copy_streams(ctx))) return rc;
     // Large batches are cut into sub-batches of whole structures (and whole residues) whose
     // host-to-device copies run on a second stream into a second set of input buffers while the
     // previous sub-batch computes: the PCIe transfer hides behind the kernels.
