@@ -72,12 +72,22 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         mnz = fminf(mnz, __shfl_xor(mnz, d, kWave)); mxz = fmaxf(mxz, __shfl_xor(mxz, d, kWave));
         mr = fmaxf(mr, __shfl_xor(mr, d, kWave));
     }
-    if (lane_id() == 0 && seg.begin + (threadIdx.x & ~(kWave - 1)) < seg.end) {
+    // one set of atomics per workgroup: a structure of a million atoms is 245 workgroups hammering
+    // the same seven words (waves without atoms contribute the neutral elements)
+    __shared__ int s_red[4][8];
+    const uint32_t wv = threadIdx.x / kWave;
+    if (lane_id() == 0) {
+        s_red[wv][0] = f2ord(mnx); s_red[wv][1] = f2ord(mny); s_red[wv][2] = f2ord(mnz);
+        s_red[wv][3] = f2ord(mxx); s_red[wv][4] = f2ord(mxy); s_red[wv][5] = f2ord(mxz);
+        s_red[wv][6] = f2ord(mr);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7u && seg.begin < seg.end) {
+        const uint32_t k = threadIdx.x;
         StructAcc *a = &b.acc[seg.sid];
-        atomicMin(&a->min_x, f2ord(mnx)); atomicMax(&a->max_x, f2ord(mxx));
-        atomicMin(&a->min_y, f2ord(mny)); atomicMax(&a->max_y, f2ord(mxy));
-        atomicMin(&a->min_z, f2ord(mnz)); atomicMax(&a->max_z, f2ord(mxz));
-        atomicMax(&a->max_r, f2ord(mr));
+        int *dst = k == 0 ? &a->min_x : k == 1 ? &a->min_y : k == 2 ? &a->min_z : k == 3 ? &a->max_x : k == 4 ? &a->max_y : k == 5 ? &a->max_z : &a->max_r;
+        if (k < 3u) atomicMin(dst, min(min(s_red[0][k], s_red[1][k]), min(s_red[2][k], s_red[3][k])));
+        else atomicMax(dst, max(max(s_red[0][k], s_red[1][k]), max(s_red[2][k], s_red[3][k])));
     }
     if (threadIdx.x == 0) {
         atomicAdd(&b.acc[seg.sid].n_atoms, seg.end - seg.begin);
