@@ -82,7 +82,7 @@ struct rsasa_context {
     bool timings_valid = false;
 
     // workspace (device)
-    DeviceBuffer segments, acc, grids, grid_sums, sid, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums, sorted_xyzr,
+    DeviceBuffer segments, acc, grids, grid_sums, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums, sorted_xyzr,
         sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
@@ -310,7 +310,6 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, ctx->acc, std::max<size_t>(S, 1) * sizeof(StructAcc)))) return rc;
     if ((rc = reserve(ctx, ctx->grids, std::max<size_t>(S, 1) * sizeof(StructGrid)))) return rc;
     if ((rc = reserve(ctx, ctx->grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
-    if ((rc = reserve(ctx, ctx->sid, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;
@@ -343,7 +342,6 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.acc = (StructAcc *)ctx->acc.p;
     v.grids = (StructGrid *)ctx->grids.p;
     v.grid_sums = (GridSums *)ctx->grid_sums.p;
-    v.sid = (uint32_t *)ctx->sid.p;
     v.sid_sorted = (uint32_t *)ctx->sid_sorted.p;
     v.deferred_list = (uint32_t *)ctx->deferred_list.p;
     v.cell_of = (uint32_t *)ctx->cell_of.p;
@@ -540,7 +538,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
-    for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
+    for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->windows, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,

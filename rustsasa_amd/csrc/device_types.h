@@ -83,7 +83,6 @@ struct BatchView {
     const Segment *segments;
     StructAcc *acc;
     StructGrid *grids;
-    uint32_t *sid;                // structure of input atom i
     uint32_t *sid_sorted;         // structure of the atom at cell-sorted position p
     uint32_t *cell_of, *rank_of;  // binning only.  Batch-wide route: cell index / arrival rank inside the cell;
                                   // k_sort_window: rank_of = sorted position of the atoms a workgroup's registers do not hold

@@ -63,7 +63,6 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         mny = fminf(mny, y); mxy = fmaxf(mxy, y);
         mnz = fminf(mnz, z); mxz = fmaxf(mxz, z);
         mr = fmaxf(mr, r);
-        b.sid[i] = seg.sid;
     }
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {
