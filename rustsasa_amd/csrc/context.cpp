@@ -323,7 +323,9 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, ctx->scan_sums, kScanBlocks * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
-    if (has_id && (rc = reserve(ctx, ctx->sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
+    // (the matrix-core kernel works on the id folds: no sorted copy of the 64-bit ids then)
+    const bool keep_ids = has_id && !occlusion_uses_mx(ctx->tuning, lat, (uint32_t)N);
+    if (keep_ids && (rc = reserve(ctx, ctx->sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
     if (has_id && (rc = reserve(ctx, ctx->sorted_id32, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->status, sizeof(BatchStatus)))) return rc;
     if (!bt.out_atom_sasa && (rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
@@ -353,7 +355,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.scan_block_sums = (uint32_t *)ctx->scan_sums.p;
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
-    v.sorted_id = has_id ? (uint64_t *)ctx->sorted_id.p : nullptr;
+    v.sorted_id = keep_ids ? (uint64_t *)ctx->sorted_id.p : nullptr;
     v.sorted_id32 = has_id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
     v.status = (BatchStatus *)ctx->status.p;
     v.atom_sasa = bt.out_atom_sasa ? bt.out_atom_sasa : (float *)ctx->atom_sasa.p;
@@ -785,7 +787,8 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if ((rc = reserve(ctx, ctx->cells, (size_t)(tail_begin + 8) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_xyzr, N * 16))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_orig, N * 4))) return rc;
-    if (id && (rc = reserve(ctx, ctx->sorted_id, N * 8))) return rc;
+    const bool keep_ids = id && !occlusion_uses_mx(ctx->tuning, lat, (uint32_t)N);
+    if (keep_ids && (rc = reserve(ctx, ctx->sorted_id, N * 8))) return rc;
     if (id && (rc = reserve(ctx, ctx->sorted_id32, N * 4))) return rc;
 
     char *h = (char *)ctx->h_small;
@@ -831,7 +834,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     v.window_capacity = (uint32_t)W;
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
-    v.sorted_id = id ? (uint64_t *)ctx->sorted_id.p : nullptr;
+    v.sorted_id = keep_ids ? (uint64_t *)ctx->sorted_id.p : nullptr;
     v.sorted_id32 = id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
     // (the single-structure call also gets its results written straight into the pinned block)
     char *hout = h + in_bytes;

@@ -95,7 +95,9 @@ struct BatchView {
     GridSums *grid_sums;   // per 256 structures: (cells, atoms) x (LDS-binned, tail), 4 x u64
     float4 *sorted_xyzr;          // cell-sorted (x, y, z, radius)
     uint32_t *sorted_orig;        // cell-sorted position -> input index
-    uint64_t *sorted_id;          // cell-sorted ids (only when id != null)
+    uint64_t *sorted_id;          // cell-sorted ids (only when id != null; null too when the matrix-core kernel takes
+                                  // the batch: it works on the folds, and the general kernel fetches the few ids it
+                                  // needs through sorted_orig)
     uint32_t *sorted_id32;        // the same folded to 32 bits (fold_id): different folds => different ids
     BatchStatus *status;
     // outputs
@@ -140,6 +142,8 @@ enum OcclusionPart : uint32_t {
 };
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
                       OcclusionPart part, hipStream_t stream);
+// Whether launch_occlusion gives a batch of n_atoms atoms to the matrix-core kernel.
+bool occlusion_uses_mx(const OcclusionTuning &tune, const Lattice &lat, uint32_t n_atoms);
 // The general kernel over the atoms the straight-line kernel deferred (see BatchView::defer_flag).
 void launch_occlusion_deferred(const BatchView &b, const Lattice &lat, hipStream_t stream);
 void launch_residue_sums(const BatchView &b, hipStream_t stream);

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                         const uint32_t p = g.sorted_base + rpos[k0 + k];
                         b.sorted_xyzr[p] = v[k];
                         b.sorted_orig[p] = i;
-                        if (pid) { b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
+                        if (pid) { if (b.sorted_id) b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
                     }
                 }
             }
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                     const uint32_t p = g.sorted_base + pos[k];
                     b.sorted_xyzr[p] = v[k];
                     b.sorted_orig[p] = i;
-                    if (pid) { b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
+                    if (pid) { if (b.sorted_id) b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
                 }
             }
         }
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
         b.sorted_orig[out0 + j] = q.x;
         if (pid) {
             b.sorted_id32[out0 + j] = q.y;
-            b.sorted_id[out0 + j] = (uint64_t)q.z | ((uint64_t)q.w << 32);
+            if (b.sorted_id) b.sorted_id[out0 + j] = (uint64_t)q.z | ((uint64_t)q.w << 32);
         }
     }
     for (uint32_t j = tid; j < total; j += 1024u) b.sid_sorted[out0 + j] = s;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
         b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
         b.sorted_orig[pos] = i;
         b.sid_sorted[pos] = s;
-        if (b.id) { const uint64_t v = b.id[i]; b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
+        if (b.id) { const uint64_t v = b.id[i]; if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
     }
 }
 

@@ -106,8 +106,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     // kMxMaxPoints with the matrix-core kernel
     // (6 = default: the matrix-core kernel once the batch has enough atoms to fill the GPU with its
     // 64-atom waves; smaller batches - single structures - finish sooner on the per-atom kernels)
-    const bool mx = tune.kernel_version >= 5 && lat.n_fused <= kMxMaxPoints &&
-                    (tune.kernel_version == 5 || b.n_atoms >= kMxMinAtoms);
+    const bool mx = occlusion_uses_mx(tune, lat, b.n_atoms);
     const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && (n_chunks <= 2 || mx) &&
                       lat.n_points - lat.n_fused <= kFastMaxRem;
     if (!fast && part == kOccHead) return;  // only the fast kernel takes a partial range
@@ -184,6 +183,12 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     } else {
         hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
     }
+}
+
+bool occlusion_uses_mx(const OcclusionTuning &tune, const Lattice &lat, uint32_t n_atoms)
+{
+    return tune.kernel_version >= 5 && tune.debug_stop == 0 && lat.n_fused <= kMxMaxPoints &&
+           lat.n_points - lat.n_fused <= kFastMaxRem && (tune.kernel_version == 5 || n_atoms >= kMxMinAtoms);
 }
 
 void launch_occlusion_deferred(const BatchView &b, const Lattice &lat, hipStream_t stream)
