@@ -312,7 +312,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, ctx->grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
     if ((rc = reserve(ctx, ctx->sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;
+    if (has_tail && (rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;  // (batch-wide binning only)
     if ((rc = reserve(ctx, ctx->rank_of, std::max<size_t>(N, 1) * 4))) return rc;
     // + 1 end marker, + 3: k_zero_cells / k_scan_* access whole 16-byte vectors up to the end marker
     if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1 + 3) * 4))) return rc;
@@ -782,7 +782,6 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if ((rc = reserve(ctx, ctx->small_out, out_bytes))) return rc;
     if ((rc = reserve(ctx, ctx->sid_sorted, N * 4))) return rc;
     if ((rc = reserve(ctx, ctx->deferred_list, N * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->cell_of, N * 4))) return rc;
     if ((rc = reserve(ctx, ctx->rank_of, N * 4))) return rc;
     if ((rc = reserve(ctx, ctx->cells, (size_t)(tail_begin + 8) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_xyzr, N * 16))) return rc;
