@@ -123,7 +123,7 @@ struct OcclusionTuning {
     int kernel_version = 6;       // 0 = all-pairs reference kernel, 3 = general culled-sweep kernel for every atom,
                                   // 4 = straight-line per-atom kernel, 5 = group-union sweep + matrix-core point
                                   // tests (4 and 5 leave the atoms they cannot take to the general kernel),
-                                  // 6 = 5 for batches of 65 536 atoms or more, 4 below
+                                  // 6 = 5 for batches of 32 768 atoms or more, 4 below
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
     uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
 };
