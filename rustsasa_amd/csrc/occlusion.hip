@@ -145,7 +145,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // waves resident) - fewer (down to 8) for smaller batches, where the last, partly filled round
             // and, for single structures, the time of one wave set the time of the call.  With many
             // points an atom is a microsecond of work and a wave's atoms share less of it: 16 rounds.
-            const bool multi = lat.n_fused > 128u;
+            const bool multi = lat.n_points > 128u;  // (the remainder points are columns of the matrix tests too)
             const uint32_t rounds = multi ? 16u : 4u, apw_max = multi ? kMxAtomsMulti : kMxAtoms;
             uint32_t apw = apw_max;
             if (tune.atoms_per_wave > 0) apw = min(tune.atoms_per_wave, apw_max);
@@ -153,9 +153,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             a3.atoms_per_wave = apw;
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
             const bool has_id = b.id != nullptr;
-            const uint32_t table = 24u * 128u * cdiv(lat.n_fused, 128u);  // (groups of 128 points)
-            if (lat.n_fused <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u, stream, a3);
-            else if (lat.n_fused <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u, stream, a3);
+            const uint32_t table = 24u * 128u * cdiv(lat.n_points, 128u);  // (groups of 128 points)
+            if (lat.n_points <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u, stream, a3);
+            else if (lat.n_points <= 112u) launch_mx<7, false, 4>(has_id, rem, b.n_atoms, 24u * 112u, stream, a3);
+            else if (lat.n_points <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u, stream, a3);
             // more points: the waves per workgroup that keep most waves on a CU (160 KB of LDS: the
             // table once per workgroup, ~3.2 KB per wave).  Multiples of four only: 9 or 14 waves per
             // workgroup spread unevenly over the four SIMDs and measured 18 % slower.
@@ -187,7 +188,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
 
 bool occlusion_uses_mx(const OcclusionTuning &tune, const Lattice &lat, uint32_t n_atoms)
 {
-    return tune.kernel_version >= 5 && tune.debug_stop == 0 && lat.n_fused <= kMxMaxPoints &&
+    return tune.kernel_version >= 5 && tune.debug_stop == 0 && lat.n_points <= kMxMaxPoints &&
            lat.n_points - lat.n_fused <= kFastMaxRem && (tune.kernel_version == 5 || n_atoms >= kMxMinAtoms);
 }
 
