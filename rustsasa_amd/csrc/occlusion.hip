@@ -153,15 +153,16 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             a3.atoms_per_wave = apw;
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
             const bool has_id = b.id != nullptr;
-            const uint32_t table = 24u * 128u * cdiv(lat.n_points, 128u);  // (groups of 128 points)
-            if (lat.n_points <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u, stream, a3);
-            else if (lat.n_points <= 112u) launch_mx<7, false, 4>(has_id, rem, b.n_atoms, 24u * 112u, stream, a3);
-            else if (lat.n_points <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u, stream, a3);
+            // (+ 16 zero entries of the f32 table: the column that pads phase B's last round)
+            const uint32_t table = 24u * 128u * cdiv(lat.n_points, 128u) + 256u;  // (groups of 128 points)
+            if (lat.n_points <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u + 256u, stream, a3);
+            else if (lat.n_points <= 112u) launch_mx<7, false, 4>(has_id, rem, b.n_atoms, 24u * 112u + 256u, stream, a3);
+            else if (lat.n_points <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u + 256u, stream, a3);
             // more points: the waves per workgroup that keep most waves on a CU (160 KB of LDS: the
             // table once per workgroup, ~3.2 KB per wave).  Multiples of four only: 9 or 14 waves per
             // workgroup spread unevenly over the four SIMDs and measured 18 % slower.
-            else if (table <= 8192u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, table, stream, a3);
-            else if (table <= 24576u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, table, stream, a3);   // 3 x 8 waves
+            else if (table <= 8192u + 256u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, table, stream, a3);
+            else if (table <= 24576u + 256u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, table, stream, a3);   // 3 x 8 waves
             else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, table, stream, a3);                        // 2 x 12 waves
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
