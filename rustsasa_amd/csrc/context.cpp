@@ -737,7 +737,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     for (size_t s = 0; s < S; s++) {
         if (so[s] > so[s + 1]) return kNotSmall;  // (the general path reports it)
         float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY}, mr = 0.0f;
-        bool finite = true;
+        bool finite = true, odd_r = false;
         for (uint32_t i = so[s]; i < so[s + 1]; i++) {
             const float p[3] = {x[i], y[i], z[i]};
             for (int k = 0; k < 3; k++) {
@@ -747,9 +747,11 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
             }
             mr = fmaxf(mr, radius[i]);
             finite &= std::isfinite(radius[i]);
+            odd_r |= !(radius[i] >= 0.0f && radius[i] <= 64.0f);
         }
         if (!finite || !small_grid(mn, mx, mr, probe, so[s + 1] - so[s], &grids[s])) return kNotSmall;
         grids[s].atom_begin = so[s];
+        grids[s].odd_radii = odd_r ? 1u : 0u;
         grids[s].sorted_base = so[s];
         grids[s].cell_base = (uint32_t)total_cells;
         total_cells += lds_cell_slots(grids[s].n_cells);

@@ -21,7 +21,8 @@ struct StructGrid {
     uint32_t sorted_base;          // first position of the structure in the cell-sorted arrays
     uint32_t in_lds;               // 1: binned by k_sort_window (fewer than 65536 atoms; 16-bit cell starts relative
                                    // to sorted_base), 0: by the batch-wide kernels (32-bit absolute cell starts)
-    uint32_t pad;
+    uint32_t odd_radii;            // 1: some radius of the structure lies outside [0, 64] or is NaN (the matrix-core
+                                   // occlusion kernel leaves such structures to the general kernel)
 };
 static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
 
@@ -33,7 +34,7 @@ struct StructAcc {
     int max_r;
     uint32_t n_atoms;      // atoms of the structure (sum over its bounds workgroups)
     uint32_t first_atom;   // smallest atom index of the structure
-    int pad;
+    int odd_radii;         // nonzero: a radius outside [0, 64] or NaN (see StructGrid::odd_radii)
 };
 
 // A contiguous slice of one structure handled by one bounds workgroup.

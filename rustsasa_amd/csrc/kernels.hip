@@ -44,7 +44,7 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
     a.max_r = f2ord(0.0f);                // fold(0.0f32, f32::max), lib.rs:262
     a.n_atoms = 0;
     a.first_atom = 0xFFFFFFFFu;
-    a.pad = 0;
+    a.odd_radii = 0;
     acc[s] = a;
 }
 
@@ -57,8 +57,10 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     float mnx = __int_as_float(0x7F800000), mny = mnx, mnz = mnx;
     float mxx = __int_as_float(0xFF800000), mxy = mxx, mxz = mxx;
     float mr = 0.0f;
+    bool odd_r = false;  // a radius outside [0, 64] (or NaN): see StructGrid::odd_radii
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
         float x = b.x[i], y = b.y[i], z = b.z[i], r = b.radius[i];
+        odd_r |= !(r >= 0.0f && r <= 64.0f);
         mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
         mny = fminf(mny, y); mxy = fmaxf(mxy, y);
         mnz = fminf(mnz, z); mxz = fmaxf(mxz, z);
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         atomicAdd(&b.acc[seg.sid].n_atoms, seg.end - seg.begin);
         atomicMin(&b.acc[seg.sid].first_atom, seg.begin);
     }
+    if (ballot64(odd_r) != 0ull && lane_id() == 0) atomicOr(&b.acc[seg.sid].odd_radii, 1);
 }
 
 // SpatialGrid::new parameters (spatial_grid.rs:35-44 with cell_size from lib.rs:76).
@@ -127,6 +130,7 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
     // 16-bit LDS counters and positions: structures with fewer than 65536 atoms are binned in LDS,
     // one k_sort_window workgroup per window of kWindowCells cells; the others by the batch-wide kernels
     g.in_lds = a.n_atoms < kLdsMaxAtoms ? 1u : 0u;
+    g.odd_radii = a.odd_radii != 0 ? 1u : 0u;
     return g;
 }
 
