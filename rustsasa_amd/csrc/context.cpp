@@ -10,8 +10,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <utility>
@@ -59,6 +62,78 @@ struct Pending {
     size_t n_points = 0;
     hipStream_t stream = nullptr;
     int attempts = 0;
+    const uint32_t *id32 = nullptr;  // nullable (pipelined host path): the ids folded by the host; batch.id is then a
+                                     // device-accessible pointer the general kernel alone reads (BatchView::id32)
+};
+
+// A few worker threads that fold 64-bit ids to 32 bits (device_utils.h fold_id) ahead of the uploads: the
+// pipelined host path then moves 4 bytes per id over the link instead of 8.  Jobs (one per sub-batch) are
+// worked off in the order they were submitted, every worker taking blocks of the current job.
+class FoldPool {
+public:
+    explicit FoldPool(unsigned n_threads)
+    {
+        for (unsigned t = 0; t < n_threads; t++) workers.emplace_back([this] { run(); });
+    }
+    ~FoldPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            quit = true;
+        }
+        cv.notify_all();
+        for (auto &w : workers) w.join();
+    }
+    // queues folding src[0 .. n) into dst; returns the job's number for wait()
+    unsigned long long submit(const uint64_t *src, uint32_t *dst, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        jobs.push_back(Job{src, dst, n, 0, 0});
+        cv.notify_all();
+        return first_job + jobs.size() - 1;
+    }
+    void wait(unsigned long long job)  // returns once that job (and every earlier one) is done
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        done_cv.wait(lk, [&] { return first_job > job; });
+    }
+
+private:
+    static constexpr size_t kBlock = 1u << 16;
+    struct Job {
+        const uint64_t *src;
+        uint32_t *dst;
+        size_t n, next, finished;  // next block to hand out, blocks finished
+    };
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return quit || (!jobs.empty() && jobs.front().next * kBlock < std::max<size_t>(jobs.front().n, 1)); });
+            if (quit) return;
+            Job &j = jobs.front();
+            const size_t blk = j.next++, n_blocks = (std::max<size_t>(j.n, 1) + kBlock - 1) / kBlock;
+            const uint64_t *s = j.src;
+            uint32_t *d = j.dst;
+            const size_t b = blk * kBlock, e = std::min(j.n, b + kBlock);
+            lk.unlock();
+            for (size_t i = b; i < e; i++) d[i] = (uint32_t)s[i] ^ ((uint32_t)(s[i] >> 32) * 0x9E3779B1u);  // fold_id
+            lk.lock();
+            // (the job is still the front one: it leaves the queue only when all its blocks are finished)
+            if (++jobs.front().finished == n_blocks) {
+                jobs.pop_front();
+                first_job++;
+                done_cv.notify_all();
+                cv.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::deque<Job> jobs;
+    unsigned long long first_job = 0;  // number of the job at the front of the queue
+    bool quit = false;
 };
 
 }  // namespace rsasa
@@ -89,6 +164,10 @@ struct rsasa_context {
     // further input / output slots of the pipelined host-buffer path (kSlots sub-batches in flight)
     DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res, in3_x, in3_y, in3_z, in3_r, in3_id, in3_res;
     DeviceBuffer atom_sasa2, out_res2, atom_sasa3, out_res3;
+    DeviceBuffer in_id32[3];                      // host-folded ids of the sub-batch in slot k
+    uint32_t *h_id32 = nullptr;                   // pinned: the folds of a whole host batch on their way to the device
+    size_t h_id32_cap = 0;
+    FoldPool *fold_pool = nullptr;                // created by the first large call with ids in pinned memory
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
     hipStream_t d2h_stream = nullptr;             // D2H of the previous sub-batch's results meanwhile
     static constexpr int kSlots = 3;
@@ -305,7 +384,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
         ctx->cell_capacity = std::max<uint64_t>(1u << 16, 20ull * N + 512ull * S);
     ctx->cell_capacity = std::min<uint64_t>(ctx->cell_capacity, 0xFFFFFFF0ull);
 
-    const bool has_id = bt.id != nullptr;
+    const bool has_id = bt.id != nullptr;  // (with pd.id32 set, bt.id is the general kernel's device-accessible copy)
     if ((rc = reserve(ctx, ctx->segments, std::max<size_t>(n_seg, 1) * sizeof(Segment)))) return rc;
     if ((rc = reserve(ctx, ctx->acc, std::max<size_t>(S, 1) * sizeof(StructAcc)))) return rc;
     if ((rc = reserve(ctx, ctx->grids, std::max<size_t>(S, 1) * sizeof(StructGrid)))) return rc;
@@ -325,6 +404,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
     // (the matrix-core kernel works on the id folds: no sorted copy of the 64-bit ids then)
     const bool keep_ids = has_id && !occlusion_uses_mx(ctx->tuning, lat, (uint32_t)N);
+    if (keep_ids && pd.id32) return fail(ctx, RSASA_ERR_INTERNAL, "folded ids on a batch the per-atom kernels take");
     if (keep_ids && (rc = reserve(ctx, ctx->sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
     if (has_id && (rc = reserve(ctx, ctx->sorted_id32, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->status, sizeof(BatchStatus)))) return rc;
@@ -336,6 +416,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
 
     BatchView v{};
     v.x = bt.x; v.y = bt.y; v.z = bt.z; v.radius = bt.radius; v.id = bt.id;
+    v.id32 = pd.id32;
     v.residue_offsets = bt.residue_offsets;
     v.n_atoms = (uint32_t)N; v.n_structures = (uint32_t)S; v.n_residues = (uint32_t)R;
     v.n_segments = (uint32_t)n_seg;
@@ -548,8 +629,10 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->in3_x, &ctx->in3_y, &ctx->in3_z, &ctx->in3_r, &ctx->in3_id, &ctx->in3_res,
                             &ctx->atom_sasa2, &ctx->out_res2, &ctx->atom_sasa3, &ctx->out_res3,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
-                            &ctx->tr_id, &ctx->tr_res})
+                            &ctx->tr_id, &ctx->tr_res, &ctx->in_id32[0], &ctx->in_id32[1], &ctx->in_id32[2]})
         release(*b);
+    delete ctx->fold_pool;
+    if (ctx->h_id32) (void)hipHostFree(ctx->h_id32);
     for (auto &kv : ctx->lattices)
         if (kv.second.d) (void)hipFree(kv.second.d);
     for (int i = 0; i < rsasa_context::kSlots; i++) {
@@ -915,8 +998,11 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         size_t max_sub = 8;
         if (const char *v = std::getenv("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
         const size_t n_sub = std::min<size_t>(max_sub, N / kSubAtoms);
-        // The first sub-batch's upload is not hidden behind anything: it gets half a share.
-        const size_t first = N / (2 * n_sub - 1), share = (N - first) / (n_sub - 1);
+        // The link is the longest leg.  The first sub-batch's upload is not hidden behind anything, and nothing hides
+        // the last one's kernels: each gets half a share (RSASA_H2H_TAIL=0: only the first).
+        static const bool half_tail = !(std::getenv("RSASA_H2H_TAIL") && std::atoi(std::getenv("RSASA_H2H_TAIL")) == 0);
+        const size_t first = half_tail ? N / (2 * n_sub - 2) : N / (2 * n_sub - 1);
+        const size_t share = half_tail ? 2 * first : (N - first) / (n_sub - 1);
         auto boundary = [&](size_t k) { return first + (k - 1) * share; };  // first atom of sub-batch k >= 1
         size_t next = 1;
         for (size_t sidx = 1; sidx < n_structures && next < n_sub; sidx++) {
@@ -955,11 +1041,61 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
-        if (id && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
+        if (id && !piped && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;  // (pipelined: below, unless the ids are folded)
         if (want_res && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
         if ((rc = reserve(ctx, *oa[k], max_atoms * 4))) return rc;
         if (want_res && (rc = reserve(ctx, *orr[k], max_res * 4))) return rc;
     }
+
+    // Ids on the pipelined path: the link is the longest leg, and the matrix-core kernel only looks at 32-bit folds
+    // of the ids.  With the caller's ids in pinned memory the host folds them (a few worker threads, one sub-batch
+    // ahead of the uploads) and 4 bytes per atom cross the link instead of 8; the general kernel reads the few full
+    // ids it needs (atoms whose folds collide) straight from the caller's array, mapped into the device's
+    // address space.  Pageable ids, or a sub-batch the per-atom kernels take: the 64-bit ids are uploaded.
+    const uint64_t *id_mapped = nullptr;
+    bool fold_ids = false;
+    if (piped && id && !std::getenv("RSASA_NO_ID_FOLD")) {
+        Lattice lat_probe;
+        void *dp = nullptr;
+        if (n_points >= 1 && n_points <= (1u << 24) && get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
+            hipHostGetDevicePointer(&dp, const_cast<uint64_t *>(id), 0) == hipSuccess && dp) {
+            fold_ids = true;
+            for (size_t c = 0; c + 1 < cut.size(); c++)
+                fold_ids &= occlusion_uses_mx(ctx->tuning, lat_probe,
+                                              (uint32_t)(structure_offsets[cut[c + 1]] - structure_offsets[cut[c]]));
+            id_mapped = (const uint64_t *)dp;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (fold_ids) {
+        for (int k = 0; k < n_slots; k++)
+            if ((rc = reserve(ctx, ctx->in_id32[k], max_atoms * 4))) return rc;
+        if (N > ctx->h_id32_cap) {
+            if (ctx->h_id32) {
+                RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+                RS_HIP(ctx, hipHostFree(ctx->h_id32));
+                ctx->h_id32 = nullptr;
+                ctx->h_id32_cap = 0;
+            }
+            const size_t cap = N + N / 4;
+            RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_id32, cap * 4, hipHostMallocDefault));
+            ctx->h_id32_cap = cap;
+        }
+        if (!ctx->fold_pool) {
+            unsigned nt = std::thread::hardware_concurrency() / 4;
+            if (const char *v = std::getenv("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
+            ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)));
+            if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
+        }
+    }
+    std::vector<unsigned long long> fold_job(cut.size(), 0);
+    // (no fold job may outlive this call: the workers read the caller's id array)
+    struct FoldDrain {
+        FoldPool *pool = nullptr;
+        unsigned long long last = 0;
+        ~FoldDrain() { if (pool) pool->wait(last); }
+    } fold_drain;
 
     // Results leave on their own stream while the next sub-batch computes.  A destination in
     // pinned (page-locked) host memory takes the copy directly; a pageable one gets it through
@@ -1004,6 +1140,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         RS_HIP(ctx, hipHostMalloc((void **)&hs.h_res, cap * sizeof(uint32_t), hipHostMallocDefault));
         hs.h_res_cap = cap;
     }
+    for (int k = 0; k < n_slots && piped && id && !fold_ids; k++)
+        if ((rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
     auto upload = [&](size_t c, hipStream_t st) -> int {
         const int k = (int)(c % kSlots);
         const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
@@ -1014,7 +1152,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
             RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
             RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
-            if (id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
+            if (fold_ids) RS_HIP(ctx, hipMemcpyAsync(ctx->in_id32[k].p, ctx->h_id32 + a0, na * 4, hipMemcpyHostToDevice, st));
+            else if (id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
         }
         if (want_res) {
             const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
@@ -1117,6 +1256,16 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
         };
         bool used[kSlots] = {};
+        if (fold_ids) {
+            // all sub-batches' folds, in order, while the uploads follow behind (the previous attempt's copies out of
+            // the pinned block have all been waited for)
+            for (size_t c = 0; c < n_sub; c++) {
+                const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
+                fold_job[c] = ctx->fold_pool->submit(id + a0, ctx->h_id32 + a0, na);
+            }
+            fold_drain.pool = ctx->fold_pool;
+            fold_drain.last = fold_job[n_sub - 1];
+        }
         for (size_t c = 0; c < n_sub; c++) {
             const int k = (int)(c % kSlots);
             if (used[k]) {
@@ -1125,8 +1274,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 check(k);
                 if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
             }
+            if (fold_ids) ctx->fold_pool->wait(fold_job[c]);
             if ((rc = upload(c, cp))) return rc;
             RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
+
             RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
             if (used[k]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k], 0));  // output slot k has left the device
             const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
@@ -1136,7 +1287,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             pd.batch.y = (const float *)by[k]->p;
             pd.batch.z = (const float *)bz[k]->p;
             pd.batch.radius = (const float *)br[k]->p;
-            pd.batch.id = id ? (const uint64_t *)bi[k]->p : nullptr;
+            pd.batch.id = fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
+            pd.id32 = fold_ids ? (const uint32_t *)ctx->in_id32[k].p : nullptr;
             pd.batch.structure_offsets_host = so[k].data();
             pd.batch.n_structures = s1 - s0;
             pd.batch.n_atoms = na;

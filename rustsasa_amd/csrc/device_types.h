@@ -77,6 +77,10 @@ struct BatchView {
     // inputs
     const float *x, *y, *z, *radius;
     const uint64_t *id;  // may be null
+    const uint32_t *id32;  // nullable: the ids already folded to 32 bits (fold_id) by the host, in input order.  When set,
+                           // the binning kernels read these instead of `id`, no sorted copy of the 64-bit ids is kept, and
+                           // `id` (device-accessible, possibly mapped host memory) is only read by the general occlusion
+                           // kernel for the few atoms whose folds collide
     const uint32_t *residue_offsets;
     uint32_t n_atoms, n_structures, n_residues, n_segments;
     float probe;

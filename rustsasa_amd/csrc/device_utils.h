@@ -104,6 +104,13 @@ __device__ __forceinline__ uint32_t load_cell_start(const uint32_t *cells, uint3
 // folds are decided on the full ids (the general kernel).
 __device__ __forceinline__ uint32_t fold_id(uint64_t id) { return (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B1u); }
 
+// The id of input atom i as the binning kernels see it: a host-folded id stands for itself (fold_id of a value
+// below 2^32 is that value).
+__device__ __forceinline__ uint64_t load_id(const uint64_t *id, const uint32_t *id32, uint32_t i)
+{
+    return id32 ? (uint64_t)id32[i] : id[i];
+}
+
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 }  // namespace

@@ -308,7 +308,8 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
     const uint32_t tid = threadIdx.x;
     const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
     const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z, *__restrict__ pr = b.radius;
-    const uint64_t *__restrict__ pid = b.id;
+    const uint32_t *__restrict__ pid32 = b.id32;
+    const uint64_t *__restrict__ pid = pid32 ? reinterpret_cast<const uint64_t *>(pid32) : b.id;  // (non-null: the batch has ids)
     uint32_t *__restrict__ rank_of = b.rank_of;  // sorted position of the atoms without a slot
     const uint32_t dim_xy = g.dim_x * g.dim_y;
     uint4 *stage = reinterpret_cast<uint4 *>(s_cnt);
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                 x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
                 if (SINGLE) {
                     kr[k0 + k] = pr[i];
-                    if (pid) kid[k0 + k] = pid[i];
+                    if (pid) kid[k0 + k] = load_id(b.id, pid32, i);
                 }
             }
             if (SINGLE) { kx[k0 + k] = x[k]; ky[k0 + k] = y[k]; kz[k0 + k] = z[k]; }
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                 } else if (rcell[k0 + k] < n_cells) {
                     const uint32_t i = a0 + tid + 1024u * (k0 + k);
                     v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
-                    if (pid) id[k] = pid[i];
+                    if (pid) id[k] = load_id(b.id, pid32, i);
                 }
             }
 #pragma unroll
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
             const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
             pos[k] = rank_of[i];  // (another window's atom: not ours to read, ignored below)
             v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
-            id[k] = pid ? pid[i] : 0ull;
+            id[k] = pid ? load_id(b.id, pid32, i) : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
         b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
         b.sorted_orig[pos] = i;
         b.sid_sorted[pos] = s;
-        if (b.id) { const uint64_t v = b.id[i]; if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
+        if (b.sorted_id32) { const uint64_t v = load_id(b.id, b.id32, i); if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
     }
 }
 

@@ -380,7 +380,7 @@ def test_kernel_variants_agree(env, monkeypatch):
 # ---- size-independent properties ----------------------------------------------------
 
 def test_small_inputs_on_the_matrix_core_kernel(monkeypatch):
-    """By default batches below 65 536 atoms take the per-atom kernels (lower latency per call), so
+    """By default batches below 32 768 atoms take the per-atom kernels (lower latency per call), so
     the small cases of this file would never reach k_occlusion_mx: force it (RSASA_OCCLUSION_KERNEL=5)
     through point counts with and without remainder points, every lane count of the remainder rule,
     duplicate ids, coincident atoms, empty and tiny structures."""
@@ -417,6 +417,43 @@ def test_small_inputs_on_the_matrix_core_kernel(monkeypatch):
             for n_points in (100, 103, 960):
                 got = c.calculate_sasa_soa(x, y, z, r, ids, PROBE, n_points)
                 assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, w)), (w, n_points)
+
+
+def test_matrix_core_kernel_hands_over_what_it_does_not_take(monkeypatch):
+    """k_occlusion_mx takes atoms whose radii and probe keep its f16 operands, its three-step quotient and the
+    remainder rule's error bound valid (probe in [0, 32], r + probe >= 0.5, r + max_r + 2 probe <= 64, every
+    radius of the structure in [0, 64]); everything else goes to the general kernel.  All of it must equal
+    the oracle: negative, zero, huge and tiny radii, large and zero probes, mixed in one batch with ordinary
+    structures."""
+    import rustsasa_amd
+    monkeypatch.setenv("RSASA_OCCLUSION_KERNEL", "5")
+    b = bw.synthetic_proteome(8, seed=5)
+    so = b.structure_offsets
+    rng = np.random.default_rng(8)
+    with rustsasa_amd.Context(0) as c:
+        for probe, scale in ((PROBE, 1.0), (0.0, 1.0), (0.05, 0.2), (33.0, 1.0), (2.0, 12.0)):
+            r = (b.radius * np.float32(scale)).astype(np.float32)
+            # structure 1: a few negative radii; 2: one sphere of radius 70; 3: zeros; 4: radii just below / above 64
+            for s, vals in ((1, (-1.0, -0.25)), (2, (70.0,)), (3, (0.0,)), (4, (63.5, 64.5))):
+                if s + 1 >= len(so):
+                    continue
+                idx = rng.choice(np.arange(so[s], so[s + 1]), 4 * len(vals), replace=False)
+                r[idx] = np.resize(np.array(vals, np.float32), idx.shape)
+            got, _ = c.calculate_sasa_batch(b.x, b.y, b.z, r, b.ids, so, probe, 100)
+            want = po.calculate_sasa_batch(b.x, b.y, b.z, r, b.ids, so, probe, 100, 8, threads=4)
+            assert np.array_equal(got, want), (probe, scale, int(np.sum(got != want)))
+
+
+def test_default_dispatch_at_the_matrix_core_threshold(ctx):
+    """Batches of 32 768 atoms or more take k_occlusion_mx, smaller ones the per-atom kernels: both sides of the
+    boundary, default settings, against the oracle."""
+    b = bw.synthetic_proteome(40, seed=19)
+    assert b.n_atoms > 40000
+    for n in (32767, 32768):
+        so = np.append(b.structure_offsets[b.structure_offsets < n], np.uint32(n)).astype(np.uint32)
+        got, _ = ctx.calculate_sasa_batch(b.x[:n], b.y[:n], b.z[:n], b.radius[:n], b.ids[:n], so, PROBE, 100)
+        want = po.calculate_sasa_batch(b.x[:n], b.y[:n], b.z[:n], b.radius[:n], b.ids[:n], so, PROBE, 100, 8, threads=4)
+        assert np.array_equal(got, want), n
 
 
 def test_permutation_invariance(ctx):
@@ -832,6 +869,21 @@ def test_host_batch_pipelined_sub_batches(ctx):
     _, r4 = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
                                      residue_offsets=b.residue_offsets, want_atoms=False, res_out=pr)
     assert np.array_equal(r4, res_dev)
+    # Ids in pinned memory cross the link as 32-bit folds (the host folds them one sub-batch ahead of the
+    # uploads); atoms whose folds collide are decided by the general kernel on the full ids, which it reads
+    # from the caller's array.  Duplicated ids (spatial_grid.rs:314, lib.rs:124: same id = same atom): the
+    # folded run equals the run with pageable ids (64-bit upload) and the oracle.
+    ids2 = b.ids.copy()
+    sel = np.arange(5, b.n_atoms - 1, 997)
+    ids2[sel + 1] = ids2[sel]
+    a5, _ = ctx.calculate_sasa_batch(pin(b.x), pin(b.y), pin(b.z), pin(b.radius), pin(ids2), b.structure_offsets, PROBE, 100)
+    a6, _ = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, ids2, b.structure_offsets, PROBE, 100)
+    assert np.array_equal(a5, a6)
+    assert not np.array_equal(a5, atom_dev)
+    for s in rng.choice(b.n_structures, 6, replace=False):
+        lo, hi = int(b.structure_offsets[s]), int(b.structure_offsets[s + 1])
+        want = po.calculate_sasa_internal(b.x[lo:hi], b.y[lo:hi], b.z[lo:hi], b.radius[lo:hi], ids2[lo:hi], PROBE, 100, 8)
+        assert np.array_equal(a5[lo:hi], want)
 
 
 def test_small_host_batches_take_the_short_path_and_agree(monkeypatch):
