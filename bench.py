@@ -8,9 +8,12 @@ proteome (4 363 structures, 100 sphere points, probe 1.4 A, ResidueLevel),
 synthesised offline-reproducibly by bench_workloads.synthetic_proteome.
 
 `value` is measured with the inputs and outputs resident in HBM (the contract's
-definition); the SURVEY 8d host-to-host rate (pinned SoA in host memory in,
-per-residue values back in host memory) is timed in the same run and printed as
-`host_to_host`.
+definition), the way a rank of a sharded run works through its stream of
+batches: step k + 1 is enqueued before step k is waited for (the library keeps
+two batches in flight per context, each in its own workspace).  The
+one-batch-at-a-time rate is printed as `one_at_a_time`; the SURVEY 8d
+host-to-host rate (pinned SoA in host memory in, per-residue values back in
+host memory) is timed in the same run and printed as `host_to_host`.
 
 Multi-GPU (`--gpus N`): one process per GPU.  Launched by the driver through
 torch.distributed.run, or - when WORLD_SIZE is not set - by this script itself,
@@ -58,7 +61,9 @@ def parse_args(argv=None):
     p.add_argument("--h2h-steps", type=int, default=10,
                    help="timed steps of the host-to-host leg (0 disables it)")
     p.add_argument("--two-steps", type=int, default=40,
-                   help="steps of the secondary two-batches-in-flight measurement (0 = skip)")
+                   help="steps of the secondary one-batch-at-a-time measurement (0 = skip)")
+    p.add_argument("--shard-of", type=int, default=0,
+                   help="one GPU only: run rank 0's shard of an M-way strong-scaling split (what each of M GPUs would get)")
     p.add_argument("--weak-steps", type=int, default=5,
                    help="timed steps of the secondary weak-scaling measurement at N > 1 (0 disables it)")
     p.add_argument("--no-ids", action="store_true", help="pass id = NULL (all atoms distinct)")
@@ -80,33 +85,43 @@ def self_launch(args):
 
 
 def cpu_baseline(batch, n_points, target_seconds):
-    """The oracle (a port of the reference's CPU path) on a bounded sample of the same workload.
-    Returns the bench-line object and the oracle's per-atom values of the sample."""
+    """The oracle (a port of the reference's CPU path) on a bounded sample of the same workload, SURVEY 8d:
+    (i) one thread, (ii) all host cores with structure-level parallelism (mirrors src/main.rs:375,439);
+    same inputs, wall clock, best of three after a warm-up.  Returns the bench-line object, the oracle's
+    per-atom values of the all-cores sample and its structure count."""
     from oracle import pyoracle as po
     threads = min(po.max_threads(), os.cpu_count() or 1)
 
-    def run(n_struct):
+    def run(n_struct, n_threads):
         e = int(batch.structure_offsets[n_struct])
         t0 = time.perf_counter()
         v = po.calculate_sasa_batch(batch.x[:e], batch.y[:e], batch.z[:e], batch.radius[:e],
                                     batch.ids[:e], batch.structure_offsets[:n_struct + 1], PROBE,
-                                    n_points, 8, threads=threads)
+                                    n_points, 8, threads=n_threads)
         return time.perf_counter() - t0, v
 
-    probe_n = min(batch.n_structures, max(threads * 4, 16))
-    run(min(probe_n, 8))  # warm up the thread pool and page in the library
-    t_probe, v = run(probe_n)
-    n = int(min(batch.n_structures, max(probe_n, probe_n * target_seconds / max(t_probe, 1e-6))))
-    t = t_probe
-    if n > probe_n:
-        t, v = run(n)
-    else:
-        n = probe_n
+    def leg(n_threads, seconds, floor):
+        probe_n = min(batch.n_structures, floor)
+        run(min(probe_n, 8), n_threads)  # warm up the thread pool and page in the library
+        t_probe, v = run(probe_n, n_threads)
+        n = int(min(batch.n_structures, max(probe_n, probe_n * seconds / max(t_probe, 1e-6))))
+        best, v = (t_probe, v) if n == probe_n else run(n, n_threads)
+        for _ in range(2):
+            t, v = run(n, n_threads)
+            best = min(best, t)
+        return n, best, v
+
+    # about a third of the budget per all-cores run, a fifth of that per one-thread run
+    n, t, v = leg(threads, target_seconds / 3.0, max(threads * 4, 16))
+    n1, t1, _ = leg(1, target_seconds / 15.0, 4)
     atoms = int(batch.structure_offsets[n])
     line = {"value": round(n / t, 3), "unit": "structures/s", "cores": threads, "kind": "port",
             "sample": f"first {n} of {batch.n_structures} structures ({atoms} atoms) of rank 0's "
                       f"workload, {n_points} points, oracle/sasa_oracle.c with OpenMP over "
-                      f"structures, {t:.1f} s wall"}
+                      f"structures, best of 3 runs, {t:.2f} s wall",
+            "one_thread": {"value": round(n1 / t1, 3), "unit": "structures/s", "cores": 1,
+                           "sample": f"first {n1} structures ({int(batch.structure_offsets[n1])} atoms), "
+                                     f"best of 3 runs, {t1:.2f} s wall"}}
     return line, v, n
 
 
@@ -127,6 +142,29 @@ def parity(batch, n_struct, want_atoms, got_atoms, got_res):
             "against": "oracle/sasa_oracle.c on the cpu_baseline sample"}
 
 
+def kernel_source_hash():
+    """sha256 over the occlusion kernels' sources: profiles/pmc_*.json carry the hash of the build they were
+    measured on, and their counter-derived fields are only printed for that build."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rustsasa_amd", "csrc")
+    for f in ("occlusion.hip", "occlusion_mx.inc", "occlusion_v3.inc", "occlusion_fast.inc", "device_utils.h", "device_types.h"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(name):
+    """A profiles/pmc_*.json file, or {} when it is missing or belongs to another build of the kernels."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}, "missing"
+    if pmc.get("kernel_source_sha16") != kernel_source_hash():
+        return {}, f"stale: profiles/{name} was measured on kernel sources {pmc.get('kernel_source_sha16')}, " \
+                   f"this build is {kernel_source_hash()} (re-run tools/profile_round.sh + tools/publish_profiles.py)"
+    return pmc, "ok"
+
+
 def aggregate(dist, dev, elapsed, n_structures, n_atoms):
     """Whole-job numbers from per-rank ones: MAX of the elapsed times, SUM of the units.
     `dist` is torch.distributed (RCCL on GPUs, gloo in the CPU tests) or None for one rank."""
@@ -139,7 +177,7 @@ def aggregate(dist, dev, elapsed, n_structures, n_atoms):
     return float(el.item()), float(units[0].item()), float(units[1].item())
 
 
-def make_workload(workload, structures, n_points, rank, world=1, scaling="weak"):
+def make_workload(workload, structures, n_points, rank, world=1, scaling="weak", shard_of=0):
     """The rank's batch of independent structures.
     weak:   every rank gets its own proteome (seed + rank);
     strong: ONE proteome (seed of rank 0), largest structures first, equal-atom shards."""
@@ -151,12 +189,12 @@ def make_workload(workload, structures, n_points, rank, world=1, scaling="weak")
         if scaling == "strong":
             full = bw.synthetic_proteome(structures, seed=bw.PROTEOME_SEED)
             sizes = np.diff(full.structure_offsets.astype(np.int64))
-            parts = bw.shard_largest_first(sizes, world)
+            parts = bw.shard_largest_first(sizes, shard_of or world)
             batch = bw.select(full, parts[rank])
             batch.shard_indices = parts[rank]
             name = (f"synthetic AlphaFold-E.coli-like proteome, {full.n_structures} structures "
-                    f"sharded largest-first over {world} GPU(s), {n_points} points, probe {PROBE}, "
-                    f"ResidueLevel")
+                    f"sharded largest-first over {shard_of or world} GPU(s), {n_points} points, probe {PROBE}, "
+                    f"ResidueLevel" + (f"; rank 0's shard of that {shard_of}-way split, alone on one GPU" if shard_of else ""))
         else:
             batch = bw.synthetic_proteome(structures, seed=bw.PROTEOME_SEED + rank)
             name = (f"synthetic AlphaFold-E.coli-like proteome, {batch.n_structures} structures/GPU, "
@@ -182,26 +220,19 @@ class DeviceRun:
         self.x, self.y, self.z, self.r = dv(batch.x), dv(batch.y), dv(batch.z), dv(batch.radius)
         self.ids = dv(batch.ids.view(np.int64)) if with_ids else None
         self.res_off = dv(batch.residue_offsets.view(np.int32))
-        self.out_atom = torch.empty(batch.n_atoms, dtype=torch.float32, device=dev)
-        self.out_res = torch.empty(batch.n_residues, dtype=torch.float32, device=dev)
+        # two sets of outputs: two batches are in flight in the timed region
+        self.outs = [(torch.empty(batch.n_atoms, dtype=torch.float32, device=dev),
+                      torch.empty(batch.n_residues, dtype=torch.float32, device=dev)) for _ in range(2)]
+        self.out_atom, self.out_res = self.outs[0]
 
-    def enqueue(self, counts=None):
+    def enqueue(self, counts=None, k=0):
         self.ctx.enqueue_device(self.x, self.y, self.z, self.r, self.ids, self.batch.structure_offsets,
-                                self.out_atom, self.res_off, self.out_res, counts, PROBE,
+                                self.outs[k][0], self.res_off, self.outs[k][1], counts, PROBE,
                                 self.n_points, stream=self.stream)
 
     def step(self, counts=None):
         self.enqueue(counts)
         self.ctx.wait()
-
-    def twin(self, ctx, stream):
-        """The same resident inputs behind another context (own workspace, stream and outputs)."""
-        import copy
-        import torch
-        t = copy.copy(self)
-        t.ctx, t.stream = ctx, stream
-        t.out_atom, t.out_res = torch.empty_like(self.out_atom), torch.empty_like(self.out_res)
-        return t
 
 
 def timed(dist, steps, fn):
@@ -249,10 +280,11 @@ def main():
 
     import rustsasa_amd
     scaling = args.scaling if args.workload == "proteome" else "weak"
+    shard_of = args.shard_of if (world == 1 and args.workload == "proteome" and scaling == "strong") else 0
     batch, n_points, name = make_workload(args.workload, args.structures, args.n_points, rank, world,
-                                          scaling)
+                                          scaling, shard_of)
     ctx = rustsasa_amd.Context(local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = None  # the context's own launch streams (one per batch in flight); its HIP events time the kernels on them
     run = DeviceRun(ctx, batch, n_points, dev, not args.no_ids, stream)
 
     # candidate counts K_i (deterministic for a given input) for the algorithmic byte count
@@ -262,27 +294,46 @@ def main():
     del kcount
     algorithmic_bytes = 20 * batch.n_atoms + 16 * k_sum  # 16 + 16*K + 4 per atom
 
-    for _ in range(args.warmup):
-        run.step()
+    # warm-up in the timed region's stepping (the second workspace is allocated by the first overlapped enqueue)
+    if args.warmup > 0:
+        run.enqueue(k=0)
+        for i in range(1, args.warmup):
+            run.enqueue(k=i % 2)
+            ctx.wait()
+        ctx.wait()
 
-    # ---- the timed region: HBM-resident inputs and outputs ----
+    # ---- the timed region: HBM-resident inputs and outputs, two batches in flight ----
+    # Step k + 1 is enqueued before step k is waited for (rsasa_batch_wait returns the OLDEST batch); the
+    # context runs them in two workspaces on two streams, so the small kernels at the start of a batch and
+    # the thin tail of its occlusion kernel overlap with the neighbour's.  Exactly `steps` batches run
+    # between the two barriers.  Kernel times: the library's HIP events on each batch's launch stream.
     ctx.enable_timing(True)
     occl_ms, grid_ms, agg_ms, cells = [], [], [], [0]
 
-    def timed_step():
-        run.step()
+    def collect():
         t = ctx.timings()
         cells[0] = int(t["n_cells"])
         occl_ms.append(t["occlusion_ms"])
         grid_ms.append(t["grid_build_ms"])
         agg_ms.append(t["aggregate_ms"])
 
-    elapsed = timed(dist, args.steps, timed_step)
+    def timed_region():
+        run.enqueue(k=0)
+        for i in range(1, args.steps):
+            run.enqueue(k=i % 2)
+            ctx.wait()
+            collect()
+        ctx.wait()
+        collect()
+
+    elapsed = timed(dist, 1, timed_region)
     ctx.enable_timing(False)
     elapsed, total_structures, total_atoms = aggregate(dist, dev, elapsed, batch.n_structures,
                                                        batch.n_atoms)
-    got_atoms = run.out_atom.cpu().numpy()
-    got_res = run.out_res.cpu().numpy()
+    got_atoms = run.outs[(args.steps - 1) % 2][0].cpu().numpy()
+    got_res = run.outs[(args.steps - 1) % 2][1].cpu().numpy()
+    outputs_equal = args.steps < 2 or bool(torch.equal(run.outs[0][1], run.outs[1][1]) and
+                                             torch.equal(run.outs[0][0], run.outs[1][0]))
 
     # ---- SURVEY 8d's definition: pinned host SoA in, per-residue values back on the host ----
     h2h = None
@@ -313,37 +364,23 @@ def main():
                              "over a copy-in, a compute and a copy-out stream",
                "residues_equal_hbm_run": bool(np.array_equal(hres, got_res))}
 
-    # ---- secondary: two batches in flight (a second context: own workspace and stream), batch k + 1
-    # enqueued before batch k is waited for.  The host's enqueue time and the small kernels of one
-    # batch then hide behind the other's occlusion kernel; `value` stays the one-batch-at-a-time rate
-    # whose kernel times the roofline is computed from.
+    # ---- secondary: one batch at a time (enqueue, wait, enqueue, ...): what a caller with a single batch sees ----
     two = None
     if args.two_steps > 0:
-        ctx2 = rustsasa_amd.Context(local_rank)
-        s2 = torch.cuda.Stream()
-        runs = [run, run.twin(ctx2, s2.cuda_stream)]
-        for r_ in runs:
-            for _ in range(3):
-                r_.step()
+        ctx.enable_timing(True)
+        seq_occl = []
 
-        def two_region():
-            k_steps = args.two_steps
-            runs[0].enqueue()
-            for i in range(1, k_steps):
-                runs[i % 2].enqueue()
-                runs[(i - 1) % 2].ctx.wait()
-            runs[(k_steps - 1) % 2].ctx.wait()
+        def seq_step():
+            run.step()
+            seq_occl.append(ctx.timings()["occlusion_ms"])
 
-        t_el = timed(dist, 1, two_region)
+        t_el = timed(dist, args.two_steps, seq_step)
+        ctx.enable_timing(False)
         t_el, t_structs, _ = aggregate(dist, dev, t_el, batch.n_structures, batch.n_atoms)
-        same = bool(torch.equal(runs[0].out_res, runs[1].out_res))
         two = {"value": round(t_structs * args.two_steps / t_el, 2), "unit": "structures/s",
                "ms_per_step": round(t_el / args.two_steps * 1e3, 4), "steps": args.two_steps,
-               "definition": "the same steps with two batches in flight: two contexts (workspaces, streams) "
-                             "alternate, batch k + 1 is enqueued before batch k is waited for",
-               "outputs_equal": same}
-        del runs
-        ctx2.close()
+               "occlusion_kernel_ms": round(float(np.mean(seq_occl)), 4),
+               "definition": "the same steps one batch at a time: each step is waited for before the next is enqueued"}
 
     # ---- secondary: weak scaling (every rank its own proteome) ----
     weak = None
@@ -362,39 +399,34 @@ def main():
 
     if rank == 0:
         occl = float(np.mean(occl_ms))
-        pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
-        except Exception:
-            pmc = {}
+        pmc, pmc_state = load_pmc("pmc_occlusion.json")
+        full_batch = world == 1 and batch.n_structures == 4363
         if args.workload == "proteome":
             achieved = algorithmic_bytes / (occl * 1e-3) / 1e9
             roofline = {"bound": "valu", "kernel": "k_occlusion", "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                         "frac_of": "SURVEY 8d algorithmic bytes (20 N + 16 sum K) / kernel time / 8 TB/s: "
-                                   "the north_star figure; the kernel itself is bound by vector-instruction "
-                                   "issue (valu_issue), its HBM-side traffic is `traffic`",
-                        "traffic": pmc.get("hbm_bytes_per_launch") if world == 1 and
-                        batch.n_structures == 4363 else None,
+                                   "the north_star figure; the kernel itself is bound by the vector + matrix ALU "
+                                   "(alu_busy), its HBM-side traffic is `traffic`",
+                        "traffic": pmc.get("hbm_bytes_per_launch") if full_batch else None,
                         "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this workload, "
-                                                     "see profiles/README.md)",
+                                                     "see profiles/README.md): " + (pmc_state if full_batch else
+                                                                                    "not this workload"),
                         "algorithmic_bytes_per_launch": algorithmic_bytes,
                         "kernel_ms": round(occl, 4)}
             vi = pmc.get("valu_insts_per_launch")
-            if vi and world == 1 and batch.n_structures == 4363:
+            if vi and full_batch:
                 rate = vi / (occl * 1e-3)
                 roofline["valu_issue"] = {"insts_per_launch": vi, "achieved_insts_per_s": round(rate, 1),
                                           "peak_insts_per_s": VALU_PEAK_INSTS,
                                           "frac": round(rate / VALU_PEAK_INSTS, 4), "source": PMC_FILE}
+            if pmc.get("alu_busy") and full_batch:
+                roofline["alu_busy"] = pmc["alu_busy"]
         else:
             # config 5 is bound by the vector ALUs: no HBM fraction is claimed.  Utilisation =
             # vector instructions the occlusion launch executed (rocprofv3 SQ_INSTS_VALU, profiles/) x 64
             # lanes x 2 flop, as if every one were a full-wave FMA, against the f32 vector peak.
-            pmcu = {}
-            try:
-                pmcu = json.load(open(os.path.join(ROOT, "profiles", "pmc_uniform1m.json")))
-            except Exception:
-                pmcu = {}
+            pmcu, _ = load_pmc("pmc_uniform1m.json")
             vi = pmcu.get("valu_insts_per_launch") if (world == 1 and batch.n_atoms == 1_000_000 and n_points == 960) else None
             achieved = vi * 128.0 / (occl * 1e-3) / 1e12 if vi else None
             roofline = {"bound": "valu", "kernel": "k_occlusion",
@@ -421,6 +453,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": name, "inputs": "resident in HBM (SoA + offsets), outputs left in HBM",
+                       "stepping": "two batches in flight (step k + 1 enqueued before step k is waited for)",
+                       "outputs_of_both_workspaces_equal": outputs_equal,
                        "structures_total": int(total_structures), "atoms_total": int(total_atoms),
                        "structures_rank0": batch.n_structures, "atoms_rank0": batch.n_atoms,
                        "residues_rank0": batch.n_residues,
@@ -438,10 +472,12 @@ def main():
         if h2h:
             line["host_to_host"] = h2h
         if two:
-            line["two_in_flight"] = two
+            line["one_at_a_time"] = two
+        if shard_of:
+            line["config"]["shard_of"] = shard_of
         if weak:
             line["weak_scaling"] = weak
-        if world == 1 and args.cpu_seconds > 0:
+        if args.cpu_seconds > 0:  # (rank 0, on its own shard at N > 1)
             line["cpu_baseline"], want, n_cmp = cpu_baseline(batch, n_points, args.cpu_seconds)
             line["parity"] = parity(batch, n_cmp, want, got_atoms, got_res)
         print(json.dumps(line), flush=True)

@@ -112,10 +112,16 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
 /* Device-resident form of the batch call: every pointer in the descriptor is
  * a DEVICE pointer on the context's GPU except structure_offsets_host, which
  * stays on the host (the launch geometry is derived from it).  The call only
- * enqueues work on `hip_stream` (a hipStream_t; NULL = the context's own
- * stream) and returns; rsasa_batch_wait() synchronises, reports deferred
- * errors and transparently re-runs the batch if the cell workspace had to
- * grow.  Buffers must stay valid until rsasa_batch_wait returns. */
+ * enqueues work on `hip_stream` (a hipStream_t; NULL = one of the context's
+ * own two streams) and returns.  Up to TWO batches may be in flight per
+ * context, each in its own workspace (a third rsasa_batch_enqueue first
+ * waits for the oldest): enqueueing batch k + 1 before waiting for batch k
+ * keeps the GPU busy across the batch boundary - what a rank of a sharded
+ * run does with its stream of batches (reference src/main.rs:375).
+ * rsasa_batch_wait() waits for the OLDEST batch in flight, reports its
+ * deferred errors and transparently re-runs it if the cell workspace had to
+ * grow; with no batch in flight it returns RSASA_OK at once.  A batch's
+ * buffers must stay valid until the rsasa_batch_wait that returns it. */
 typedef struct rsasa_device_batch {
     const float *x, *y, *z, *radius;       /* [n_atoms] device */
     const uint64_t *id;                    /* [n_atoms] device, or NULL */

@@ -64,6 +64,7 @@ struct Pending {
     int attempts = 0;
     const uint32_t *id32 = nullptr;  // nullable (pipelined host path): the ids folded by the host; batch.id is then a
                                      // device-accessible pointer the general kernel alone reads (BatchView::id32)
+    int ws = 0;                      // the workspace (and host slot) the batch runs in
 };
 
 // A few worker threads that fold 64-bit ids to 32 bits (device_utils.h fold_id) ahead of the uploads: the
@@ -147,7 +148,6 @@ struct rsasa_context {
     std::string last_error;
     int simd_width = 8;
     bool timing = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool small_path = true;                       // RSASA_SMALL_PATH=0: small host batches take the general path too
     bool overlap_tail = false;                    // RSASA_OVERLAP_TAIL=1: bin the tail on the side stream, next to the first
                                                   // occlusion launch (only batches with a structure of 65 536 atoms or more have a tail now)
@@ -156,9 +156,25 @@ struct rsasa_context {
     rsasa_timings_t timings{};
     bool timings_valid = false;
 
-    // workspace (device)
-    DeviceBuffer segments, acc, grids, grid_sums, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums, sorted_xyzr,
-        sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
+    // Workspace (device) of one batch in flight.  Two of them: rsasa_batch_enqueue starts batch k + 1 in the other
+    // one (on the context's second stream) while batch k still runs - the small kernels at the start and the thin
+    // tail of the occlusion kernel at the end of a batch then overlap with its neighbour's.  Host slot w serves
+    // workspace w.  Everything else (host-pointer entry points, sub-batches of the pipelined host path) runs in
+    // workspace 0.
+    struct Workspace {
+        DeviceBuffer segments, acc, grids, grid_sums, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums,
+            sorted_xyzr, sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
+        hipEvent_t ev[5] = {};  // timing (rsasa_context_enable_timing): start, grid built, occlusion starts / has run, sums done
+        hipEvent_t ev_occ = nullptr;  // the batch's occlusion kernels have run (the other workspace's batch starts its own
+        bool occ_recorded = false;    // behind it: two occlusion kernels sharing the CUs only slow each other down)
+    } ws[2];
+    static constexpr int kInFlight = 2;
+    hipStream_t stream2 = nullptr;                // launch stream of workspace 1 (created by the first overlapped enqueue)
+    DeviceBuffer &segments = ws[0].segments, &acc = ws[0].acc, &grids = ws[0].grids, &grid_sums = ws[0].grid_sums,
+                 &sid_sorted = ws[0].sid_sorted, &deferred_list = ws[0].deferred_list, &cell_of = ws[0].cell_of,
+                 &rank_of = ws[0].rank_of, &cells = ws[0].cells, &windows = ws[0].windows, &scan_sums = ws[0].scan_sums,
+                 &sorted_xyzr = ws[0].sorted_xyzr, &sorted_orig = ws[0].sorted_orig, &sorted_id = ws[0].sorted_id,
+                 &sorted_id32 = ws[0].sorted_id32, &status = ws[0].status, &atom_sasa = ws[0].atom_sasa;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
     // further input / output slots of the pipelined host-buffer path (kSlots sub-batches in flight)
@@ -194,7 +210,8 @@ struct rsasa_context {
     uint64_t cell_capacity = 0;
 
     std::map<std::pair<size_t, int>, LatticeEntry> lattices;
-    Pending pending;
+    Pending pending[2];   // device batches in flight, oldest first: pending[head], pending[head ^ 1]
+    int head = 0, n_pending = 0;
     OcclusionTuning tuning;
 };
 
@@ -290,8 +307,8 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
         for (const auto &kv : ctx->lattices) cached_bytes += 7 * sizeof(float) * (size_t)kv.second.padded;
         if (ctx->lattices.size() >= 16 || cached_bytes > (64u << 20)) {
             RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->pending.active && ctx->pending.stream != ctx->stream)
-                RS_HIP(ctx, hipStreamSynchronize(ctx->pending.stream));
+            for (const Pending &pd : ctx->pending)
+                if (pd.active && pd.stream != ctx->stream) RS_HIP(ctx, hipStreamSynchronize(pd.stream));
             for (auto &kv : ctx->lattices)
                 if (kv.second.d) (void)hipFree(kv.second.d);
             ctx->lattices.clear();
@@ -344,6 +361,7 @@ int ensure_copy_streams(rsasa_context *ctx)
 
 int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot &hs)
 {
+    rsasa_context::Workspace &W = ctx->ws[pd.ws];
     const rsasa_device_batch_t &bt = pd.batch;
     const size_t N = bt.n_atoms, S = bt.n_structures, R = bt.n_residues;
     hipStream_t st = pd.stream;
@@ -360,7 +378,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     }
     if (n_seg > hs.h_segments_cap) {
         if (hs.h_segments) {
-            RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            RS_HIP(ctx, hipStreamSynchronize(pd.stream));
             RS_HIP(ctx, hipHostFree(hs.h_segments));
             hs.h_segments = nullptr;
             hs.h_segments_cap = 0;
@@ -385,33 +403,33 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     ctx->cell_capacity = std::min<uint64_t>(ctx->cell_capacity, 0xFFFFFFF0ull);
 
     const bool has_id = bt.id != nullptr;  // (with pd.id32 set, bt.id is the general kernel's device-accessible copy)
-    if ((rc = reserve(ctx, ctx->segments, std::max<size_t>(n_seg, 1) * sizeof(Segment)))) return rc;
-    if ((rc = reserve(ctx, ctx->acc, std::max<size_t>(S, 1) * sizeof(StructAcc)))) return rc;
-    if ((rc = reserve(ctx, ctx->grids, std::max<size_t>(S, 1) * sizeof(StructGrid)))) return rc;
-    if ((rc = reserve(ctx, ctx->grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
-    if ((rc = reserve(ctx, ctx->sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
-    if (has_tail && (rc = reserve(ctx, ctx->cell_of, std::max<size_t>(N, 1) * 4))) return rc;  // (batch-wide binning only)
-    if ((rc = reserve(ctx, ctx->rank_of, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, W.segments, std::max<size_t>(n_seg, 1) * sizeof(Segment)))) return rc;
+    if ((rc = reserve(ctx, W.acc, std::max<size_t>(S, 1) * sizeof(StructAcc)))) return rc;
+    if ((rc = reserve(ctx, W.grids, std::max<size_t>(S, 1) * sizeof(StructGrid)))) return rc;
+    if ((rc = reserve(ctx, W.grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
+    if ((rc = reserve(ctx, W.sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, W.deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
+    if (has_tail && (rc = reserve(ctx, W.cell_of, std::max<size_t>(N, 1) * 4))) return rc;  // (batch-wide binning only)
+    if ((rc = reserve(ctx, W.rank_of, std::max<size_t>(N, 1) * 4))) return rc;
     // + 1 end marker, + 3: k_zero_cells / k_scan_* access whole 16-byte vectors up to the end marker
-    if ((rc = reserve(ctx, ctx->cells, (size_t)(ctx->cell_capacity + 1 + 3) * 4))) return rc;
+    if ((rc = reserve(ctx, W.cells, (size_t)(ctx->cell_capacity + 1 + 3) * 4))) return rc;
     // one k_sort_window workgroup per window of kWindowCells 16-bit cell entries (two per entry of the cell
     // array), at most one partly filled window per structure: whatever fits the cell array fits this list
     const uint64_t window_capacity = std::min<uint64_t>(2 * ctx->cell_capacity / kWindowCells + S + 1, 0x7FFFFFFFull);
-    if ((rc = reserve(ctx, ctx->windows, (size_t)window_capacity * sizeof(uint2)))) return rc;
-    if ((rc = reserve(ctx, ctx->scan_sums, kScanBlocks * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
-    if ((rc = reserve(ctx, ctx->sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, W.windows, (size_t)window_capacity * sizeof(uint2)))) return rc;
+    if ((rc = reserve(ctx, W.scan_sums, kScanBlocks * 4))) return rc;
+    if ((rc = reserve(ctx, W.sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
+    if ((rc = reserve(ctx, W.sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
     // (the matrix-core kernel works on the id folds: no sorted copy of the 64-bit ids then)
     const bool keep_ids = has_id && !occlusion_uses_mx(ctx->tuning, lat, (uint32_t)N);
     if (keep_ids && pd.id32) return fail(ctx, RSASA_ERR_INTERNAL, "folded ids on a batch the per-atom kernels take");
-    if (keep_ids && (rc = reserve(ctx, ctx->sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
-    if (has_id && (rc = reserve(ctx, ctx->sorted_id32, std::max<size_t>(N, 1) * 4))) return rc;
-    if ((rc = reserve(ctx, ctx->status, sizeof(BatchStatus)))) return rc;
-    if (!bt.out_atom_sasa && (rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
+    if (keep_ids && (rc = reserve(ctx, W.sorted_id, std::max<size_t>(N, 1) * 8))) return rc;
+    if (has_id && (rc = reserve(ctx, W.sorted_id32, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, W.status, sizeof(BatchStatus)))) return rc;
+    if (!bt.out_atom_sasa && (rc = reserve(ctx, W.atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
 
     if (n_seg)
-        RS_HIP(ctx, hipMemcpyAsync(ctx->segments.p, hs.h_segments, n_seg * sizeof(Segment),
+        RS_HIP(ctx, hipMemcpyAsync(W.segments.p, hs.h_segments, n_seg * sizeof(Segment),
                                    hipMemcpyHostToDevice, st));
 
     BatchView v{};
@@ -421,33 +439,37 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.n_atoms = (uint32_t)N; v.n_structures = (uint32_t)S; v.n_residues = (uint32_t)R;
     v.n_segments = (uint32_t)n_seg;
     v.probe = pd.probe;
-    v.segments = (const Segment *)ctx->segments.p;
-    v.acc = (StructAcc *)ctx->acc.p;
-    v.grids = (StructGrid *)ctx->grids.p;
-    v.grid_sums = (GridSums *)ctx->grid_sums.p;
-    v.sid_sorted = (uint32_t *)ctx->sid_sorted.p;
-    v.deferred_list = (uint32_t *)ctx->deferred_list.p;
-    v.cell_of = (uint32_t *)ctx->cell_of.p;
-    v.rank_of = (uint32_t *)ctx->rank_of.p;
-    v.cells = (uint32_t *)ctx->cells.p;
+    v.segments = (const Segment *)W.segments.p;
+    v.acc = (StructAcc *)W.acc.p;
+    v.grids = (StructGrid *)W.grids.p;
+    v.grid_sums = (GridSums *)W.grid_sums.p;
+    v.sid_sorted = (uint32_t *)W.sid_sorted.p;
+    v.deferred_list = (uint32_t *)W.deferred_list.p;
+    v.cell_of = (uint32_t *)W.cell_of.p;
+    v.rank_of = (uint32_t *)W.rank_of.p;
+    v.cells = (uint32_t *)W.cells.p;
     v.cell_capacity = ctx->cell_capacity;
-    v.windows = (uint2 *)ctx->windows.p;
+    v.windows = (uint2 *)W.windows.p;
     v.window_capacity = (uint32_t)window_capacity;
-    v.scan_block_sums = (uint32_t *)ctx->scan_sums.p;
-    v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
-    v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;
-    v.sorted_id = keep_ids ? (uint64_t *)ctx->sorted_id.p : nullptr;
-    v.sorted_id32 = has_id ? (uint32_t *)ctx->sorted_id32.p : nullptr;
-    v.status = (BatchStatus *)ctx->status.p;
-    v.atom_sasa = bt.out_atom_sasa ? bt.out_atom_sasa : (float *)ctx->atom_sasa.p;
+    v.scan_block_sums = (uint32_t *)W.scan_sums.p;
+    v.sorted_xyzr = (float4 *)W.sorted_xyzr.p;
+    v.sorted_orig = (uint32_t *)W.sorted_orig.p;
+    v.sorted_id = keep_ids ? (uint64_t *)W.sorted_id.p : nullptr;
+    v.sorted_id32 = has_id ? (uint32_t *)W.sorted_id32.p : nullptr;
+    v.status = (BatchStatus *)W.status.p;
+    v.atom_sasa = bt.out_atom_sasa ? bt.out_atom_sasa : (float *)W.atom_sasa.p;
     v.residue_sasa = (R && bt.residue_offsets) ? bt.out_residue_sasa : nullptr;
     v.neighbor_counts = bt.out_neighbor_counts;
 
     // Launch stream: grids -> LDS binning -> occlusion of the LDS-binned structures -> (join) ->
     // occlusion of the tail -> sums.  Side stream (forked after the LDS binning): the tail's
     // batch-wide binning, which is bandwidth bound and runs next to the compute-bound occlusion kernel.
-    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[0], st));
     launch_grid_prepare(v, st);
+    // Two batches in flight: this one's grid build (bandwidth bound, many small kernels) runs beside the other one's
+    // occlusion kernel, its occlusion kernel behind it.
+    rsasa_context::Workspace &other = ctx->ws[pd.ws ^ 1];
+    const bool chain = other.occ_recorded && !std::getenv("RSASA_FREE_OVERLAP");
     const bool overlap = ctx->overlap_tail && has_tail;
     if (overlap && (rc = ensure_side_stream(ctx))) return rc;
     if (overlap) {
@@ -458,36 +480,43 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
         RS_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
         launch_sort_tail(v, ctx->side_stream);
         RS_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
-        if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[1], st));
+        if (chain) RS_HIP(ctx, hipStreamWaitEvent(st, other.ev_occ, 0));
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[2], st));
         launch_occlusion(v, lat, ctx->tuning, kOccHead, st);
         RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         launch_occlusion(v, lat, ctx->tuning, kOccRest, st);
     } else {
         launch_sort_lds(v, st);
         if (has_tail) launch_sort_tail(v, st);
-        if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[1], st));
+        if (chain) RS_HIP(ctx, hipStreamWaitEvent(st, other.ev_occ, 0));
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[2], st));
         launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
     }
-    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+    RS_HIP(ctx, hipEventRecord(W.ev_occ, st));
+    W.occ_recorded = true;
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[3], st));
     launch_residue_sums(v, st);
-    if (ctx->timing) RS_HIP(ctx, hipEventRecord(ctx->ev[3], st));
-    RS_HIP(ctx, hipMemcpyAsync(hs.h_status, ctx->status.p, sizeof(BatchStatus),
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[4], st));
+    RS_HIP(ctx, hipMemcpyAsync(hs.h_status, W.status.p, sizeof(BatchStatus),
                                hipMemcpyDeviceToHost, st));
     RS_HIP(ctx, hipGetLastError());
     return RSASA_OK;
 }
 
-int wait_pending(rsasa_context *ctx)
+// Waits for the batch in `pd` (re-running it if the cell array had to grow) and reports its deferred errors.
+int wait_one(rsasa_context *ctx, Pending &pd)
 {
-    Pending &pd = ctx->pending;
     if (!pd.active) return RSASA_OK;
+    rsasa_context::Workspace &W = ctx->ws[pd.ws];
     for (;;) {
         hipError_t e = hipStreamSynchronize(pd.stream);
         if (e != hipSuccess) {
             pd.active = false;
             return fail(ctx, RSASA_ERR_HIP, "hipStreamSynchronize", e);
         }
-        const BatchStatus stt = *ctx->slot[0].h_status;
+        const BatchStatus stt = *ctx->slot[pd.ws].h_status;
         if (stt.grid_too_large) {
             pd.active = false;
             return fail(ctx, RSASA_ERR_GRID_TOO_LARGE,
@@ -501,10 +530,10 @@ int wait_pending(rsasa_context *ctx)
         if (!stt.overflow) {
             if (ctx->timing) {
                 float g = 0, o = 0, a = 0, t = 0;
-                (void)hipEventElapsedTime(&g, ctx->ev[0], ctx->ev[1]);
-                (void)hipEventElapsedTime(&o, ctx->ev[1], ctx->ev[2]);
-                (void)hipEventElapsedTime(&a, ctx->ev[2], ctx->ev[3]);
-                (void)hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[3]);
+                (void)hipEventElapsedTime(&g, W.ev[0], W.ev[1]);
+                (void)hipEventElapsedTime(&o, W.ev[2], W.ev[3]);
+                (void)hipEventElapsedTime(&a, W.ev[3], W.ev[4]);
+                (void)hipEventElapsedTime(&t, W.ev[0], W.ev[4]);
                 ctx->timings = rsasa_timings_t{g, o, a, t, stt.grid_cells, pd.batch.n_atoms, stt.deferred};
                 ctx->timings_valid = true;
             }
@@ -518,12 +547,34 @@ int wait_pending(rsasa_context *ctx)
         }
         ctx->cell_capacity = stt.total_cells + stt.total_cells / 8 + 1024;
         pd.attempts++;
-        int rc = enqueue_batch(ctx, pd, ctx->slot[0]);
+        int rc = enqueue_batch(ctx, pd, ctx->slot[pd.ws]);
         if (rc) {
             pd.active = false;
             return rc;
         }
     }
+}
+
+// The oldest batch in flight (rsasa_batch_wait), or every one (entry points that need the whole context).
+int wait_oldest(rsasa_context *ctx)
+{
+    if (ctx->n_pending == 0) return RSASA_OK;
+    const int rc = wait_one(ctx, ctx->pending[ctx->head]);
+    ctx->head ^= 1;
+    ctx->n_pending--;
+    return rc;
+}
+
+int wait_pending(rsasa_context *ctx)
+{
+    int first = RSASA_OK;
+    while (ctx->n_pending) {
+        const int rc = wait_one(ctx, ctx->pending[ctx->head]);
+        if (rc && !first) first = rc;
+        ctx->head ^= 1;
+        ctx->n_pending--;
+    }
+    return first;
 }
 
 rsasa_context *g_default_ctx = nullptr;
@@ -590,7 +641,10 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     DeviceGuard guard(device);
     hipError_t e = guard.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    for (int w = 0; w < rsasa_context::kInFlight; w++) {
+        for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ws[w].ev[i]);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws[w].ev_occ, hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
@@ -620,6 +674,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (!ctx) return RSASA_OK;
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->windows, &ctx->scan_sums, &ctx->sorted_xyzr,
@@ -641,8 +696,19 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
         if (ctx->slot[i].h_res) (void)hipHostFree(ctx->slot[i].h_res);
         if (ctx->ev_done[i]) (void)hipEventDestroy(ctx->ev_done[i]);
     }
-    for (int i = 0; i < 4; i++)
-        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int w = 0; w < rsasa_context::kInFlight; w++) {
+        for (int i = 0; i < 5; i++)
+            if (ctx->ws[w].ev[i]) (void)hipEventDestroy(ctx->ws[w].ev[i]);
+        if (ctx->ws[w].ev_occ) (void)hipEventDestroy(ctx->ws[w].ev_occ);
+    }
+    {
+        rsasa_context::Workspace &w1 = ctx->ws[1];
+        for (DeviceBuffer *b : {&w1.segments, &w1.acc, &w1.grids, &w1.grid_sums, &w1.sid_sorted, &w1.deferred_list, &w1.cell_of, &w1.rank_of,
+                                &w1.cells, &w1.windows, &w1.scan_sums, &w1.sorted_xyzr, &w1.sorted_orig, &w1.sorted_id, &w1.sorted_id32,
+                                &w1.status, &w1.atom_sasa})
+            release(*b);
+    }
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (int i = 0; i < rsasa_context::kSlots; i++)
         if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
     for (int i = 0; i < rsasa_context::kSlots; i++) {
@@ -737,17 +803,22 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
         return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "out_residue_sasa is NULL");
 
     RS_DEVICE(ctx);
-    if (ctx->pending.active) {
-        rc = wait_pending(ctx);
-        if (rc) return rc;
-    }
-    ctx->pending.batch = *batch;
-    ctx->pending.probe = probe_radius;
-    ctx->pending.n_points = n_points;
-    ctx->pending.stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    ctx->pending.attempts = 0;
-    rc = enqueue_batch(ctx, ctx->pending, ctx->slot[0]);
-    ctx->pending.active = (rc == RSASA_OK);
+    // Up to two batches in flight, each in its own workspace; a third waits for the oldest one.
+    while (ctx->n_pending >= rsasa_context::kInFlight)
+        if ((rc = wait_oldest(ctx))) return rc;
+    const int w = ctx->n_pending ? ctx->pending[ctx->head].ws ^ 1 : 0;
+    if (w == 1 && !hip_stream && !ctx->stream2)
+        RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    Pending &pd = ctx->pending[ctx->head ^ (ctx->n_pending ? 1 : 0)];
+    pd = Pending{};
+    pd.batch = *batch;
+    pd.probe = probe_radius;
+    pd.n_points = n_points;
+    pd.stream = hip_stream ? (hipStream_t)hip_stream : (w ? ctx->stream2 : ctx->stream);
+    pd.ws = w;
+    rc = enqueue_batch(ctx, pd, ctx->slot[w]);
+    pd.active = (rc == RSASA_OK);
+    if (pd.active) ctx->n_pending++;
     return rc;
 }
 
@@ -757,7 +828,7 @@ int rsasa_batch_wait(rsasa_context_t *ctx)
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
-    return wait_pending(ctx);
+    return wait_oldest(ctx);
 }
 
 namespace {
@@ -980,7 +1051,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
-    if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+    if (ctx->n_pending && (rc = wait_pending(ctx))) return rc;
     if (ctx->small_path) {
         rc = run_small_host_batch(ctx, x, y, z, radius, id, structure_offsets, n_structures, probe_radius, n_points,
                                   out_atom_sasa, want_res ? residue_offsets : nullptr, want_res ? n_residues : 0,
@@ -1383,7 +1454,7 @@ int rsasa_calculate_sasa_trajectory(rsasa_context_t *ctx, const float *xyz, size
     }
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
-    if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+    if (ctx->n_pending && (rc = wait_pending(ctx))) return rc;
     hipStream_t st = ctx->stream;
     // topology columns once
     if ((rc = reserve(ctx, ctx->tr_r, n_atoms * 4))) return rc;
@@ -1466,7 +1537,7 @@ int rsasa_segment_sums(rsasa_context_t *ctx, const float *values, size_t n_value
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "offsets must be non-decreasing");
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
-    if (ctx->pending.active && (rc = wait_pending(ctx))) return rc;
+    if (ctx->n_pending && (rc = wait_pending(ctx))) return rc;
     if ((rc = reserve(ctx, ctx->atom_sasa, std::max<size_t>(n_values, 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->in_res, (n_segments + 1) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->out_res, n_segments * 4))) return rc;

@@ -76,7 +76,7 @@ class Context:
         self.device = device
         if simd_width != 8:
             self.set_simd_width(simd_width)
-        self._keepalive = None
+        self._keepalive = []  # buffers of the batches in flight, oldest first
 
     def close(self):
         if getattr(self, "_h", None):
@@ -178,7 +178,9 @@ class Context:
         """Enqueue one batch whose arrays are torch CUDA(=HIP) tensors.
 
         `stream` is a raw hipStream_t value (e.g. torch.cuda.current_stream().cuda_stream);
-        None uses the context's own stream.  Call wait() before reading outputs.
+        None uses the context's own streams.  Up to two batches may be in flight (the library gives
+        each its own workspace; a third enqueue first waits for the oldest): wait() waits for the
+        OLDEST batch in flight, so enqueue(k + 1) followed by wait() returns batch k's results.
         """
         so = np.ascontiguousarray(structure_offsets_host, dtype=np.uint32)
 
@@ -196,22 +198,30 @@ class Context:
         b.out_atom_sasa = dp(out_atom_sasa)
         b.out_residue_sasa = dp(out_residue_sasa)
         b.out_neighbor_counts = dp(out_neighbor_counts)
-        # The library may re-run a batch from wait(), and rsasa_batch_enqueue first waits for the
-        # batch enqueued before: the previous batch's buffers stay alive until the call returns,
-        # this batch's until its wait().
-        previous = self._keepalive
+        # The library may re-run a batch from its wait(): a batch's buffers stay alive until it has been
+        # waited for.  With two batches already in flight rsasa_batch_enqueue waits for the oldest itself.
         keep = (so, x, y, z, radius, ids, residue_offsets, out_atom_sasa, out_residue_sasa,
                 out_neighbor_counts)
+        full = len(self._keepalive) >= 2
         try:
             self._check(self._lib.rsasa_batch_enqueue(self._h, C.byref(b), probe_radius, n_points,
                                                       C.c_void_p(stream) if stream else None))
         finally:
-            del previous
-        self._keepalive = keep
+            if full:
+                self._keepalive.pop(0)
+        self._keepalive.append(keep)
 
     def wait(self):
-        self._check(self._lib.rsasa_batch_wait(self._h))
-        self._keepalive = None
+        """Waits for the oldest batch in flight (no batch in flight: returns at once)."""
+        try:
+            self._check(self._lib.rsasa_batch_wait(self._h))
+        finally:
+            if self._keepalive:
+                self._keepalive.pop(0)
+
+    def wait_all(self):
+        while self._keepalive:
+            self.wait()
 
     # ---- measurement -------------------------------------------------------
     def enable_timing(self, enable: bool = True):

@@ -1,49 +1,34 @@
 #!/usr/bin/env python3
-"""What two batches in flight would give: two contexts (two workspaces, two streams) alternate on the
-same device-resident batch; batch k + 1 is enqueued before batch k is waited for.  An experiment for
-DESIGN.md (the product API holds one batch per context)."""
+"""Two batches in flight inside ONE context (two workspaces, two streams) against one batch at a time, for the whole
+proteome batch and for one rank's shard of an M-way split.  usage: tools/bench_two_in_flight.py [M ...]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
-import bench_workloads as bw
+import bench, bench_workloads as bw
 import rustsasa_amd
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else bw.PROTEOME_STRUCTURES
-b = bw.synthetic_proteome(n, seed=bw.PROTEOME_SEED)
 dev = torch.device("cuda:0")
-t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-x, y, z, r = t(b.x), t(b.y), t(b.z), t(b.radius)
-ids = t(b.ids.view(np.int64))
-ro = t(b.residue_offsets.view(np.int32))
-outs = [torch.zeros(b.n_atoms, dtype=torch.float32, device=dev) for _ in range(2)]
-ress = [torch.zeros(b.n_residues, dtype=torch.float32, device=dev) for _ in range(2)]
-streams = [torch.cuda.Stream() for _ in range(2)]
-ctxs = [rustsasa_amd.Context(0) for _ in range(2)]
-
-
-def enq(k):
-    ctxs[k].enqueue_device(x, y, z, r, ids, b.structure_offsets, outs[k], ro, ress[k], None, 1.4, 100,
-                           stream=streams[k].cuda_stream)
-
-
-K = 100
-for mode in ("one in flight", "two in flight"):
-    for k in range(2):
-        for _ in range(3):
-            enq(k); ctxs[k].wait()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    if mode == "one in flight":
-        for i in range(K):
-            enq(0); ctxs[0].wait()
-    else:
-        enq(0)
-        for i in range(1, K):
-            enq(i % 2)
-            ctxs[(i - 1) % 2].wait()
-        ctxs[(K - 1) % 2].wait()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / K
-    print(f"{b.n_structures} structures, {mode}: {dt * 1e3:.4f} ms per batch, {b.n_structures / dt:.0f} structures/s")
-assert torch.equal(outs[0], outs[1])
+for m in [int(a) for a in sys.argv[1:]] or [1, 8]:
+    batch, n_points, _ = bench.make_workload("proteome", None, None, 0, 1, "strong", m if m > 1 else 0)
+    with rustsasa_amd.Context(0) as ctx:
+        run = bench.DeviceRun(ctx, batch, n_points, dev, True, None)
+        for _ in range(5):
+            run.step()
+        for timing in (False, True):
+            ctx.enable_timing(timing)
+            steps = 200 if m > 1 else 40
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(steps):
+                run.step()
+            torch.cuda.synchronize(); seq = (time.perf_counter() - t0) / steps
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            run.enqueue(k=0)
+            for i in range(1, steps):
+                run.enqueue(k=i % 2)
+                ctx.wait()
+            ctx.wait()
+            torch.cuda.synchronize(); two = (time.perf_counter() - t0) / steps
+            print(f"shard 1/{m}: {batch.n_structures} structures, {batch.n_atoms} atoms, timing events {timing}: "
+                  f"one at a time {seq * 1e3:.4f} ms/step, two in flight {two * 1e3:.4f} ms/step")

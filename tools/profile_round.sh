@@ -4,7 +4,8 @@
 #   bench.json                 default `python bench.py` line (with the CPU baseline leg)
 #   kernel_stats.csv           rocprofv3 --kernel-trace --stats of `bench.py --steps 20 --warmup 3 --cpu-seconds 0`
 #   bench_under_rocprof.json   the bench line of that profiled run
-#   pmc.txt                    PMC summaries of the occlusion kernel (separate passes, no tracing)
+#   pmc.txt                    PMC summaries of the occlusion kernel (separate passes, no tracing): instruction mix, waits,
+#                              matrix-pipe busy / co-execution cycles, GRBM_GUI_ACTIVE (clock), FETCH_SIZE, WRITE_SIZE, TCC hits
 #   bench_uniform1m.json, single_and_pcie.json, files_mode.json
 tag=${1:-round}
 out=gpurun_out/$tag
@@ -17,6 +18,8 @@ grep '^{"metric"' $out/trace.log | tail -1 > $out/bench_under_rocprof.json
 one="python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --h2h-steps 0 --two-steps 0"
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d $out/pmc_a -- $one > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_IDX_ACTIVE --output-format csv -d $out/pmc_b -- $one > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $out/pmc_c -- $one > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_g -- $one > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- $one > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- $one > /dev/null 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_tcc -- $one > /dev/null 2>&1
@@ -27,5 +30,5 @@ rm -rf $out/pmcu_a
 python3 bench.py --workload uniform1m --cpu-seconds 0 --h2h-steps 0 --two-steps 0 > $out/u1m.log 2>&1; tail -1 $out/u1m.log > $out/bench_uniform1m.json
 python3 tools/bench_single.py 2>/dev/null > $out/single_and_pcie.json
 python3 tools/bench_files.py --files 4363 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json
-rm -rf $out/trace $out/pmc_a $out/pmc_b $out/pmc_fetch $out/pmc_write $out/pmc_tcc
+rm -rf $out/trace $out/pmc_a $out/pmc_b $out/pmc_c $out/pmc_g $out/pmc_fetch $out/pmc_write $out/pmc_tcc
 ls -la $out; cat $out/bench.json; cat $out/bench_under_rocprof.json; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc.txt

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "round2_final"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "round3_final"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
@@ -29,6 +29,9 @@ def val(name):
 kernel = re.search(r"dispatch \d+: (.*?) grid=", txt).group(1).strip()
 
 
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_hash: the build these counters belong to)
+
 fetch_kb, write_kb = val("FETCH_SIZE"), val("WRITE_SIZE")
 hit, miss = val("TCC_HIT_sum"), val("TCC_MISS_sum")
 bench = json.load(open(os.path.join(src, "bench.json")))
@@ -46,7 +49,26 @@ out = {
     "tcc_hit_rate": round(hit / (hit + miss), 4),
     "valu_insts_per_launch": val("SQ_INSTS_VALU"),
     "salu_insts_per_launch": val("SQ_INSTS_SALU"),
+    "kernel_source_sha16": bench.kernel_source_hash(),
 }
+try:
+    # vector + matrix ALU occupancy: plain vector instructions at the 2.7 cycles each costs a SIMD at full occupancy
+    # (tools/microbench_issue.hip), matrix instructions at the cycles SQ_VALU_MFMA_BUSY_CYCLES counts for them, over the
+    # kernel's cycles on the 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+    mfma, busy, coexec, gui = val("SQ_INSTS_MFMA"), val("SQ_VALU_MFMA_BUSY_CYCLES"), val("SQ_VALU_MFMA_COEXEC_CYCLES"), val("GRBM_GUI_ACTIVE")
+    cyc = gui / 8.0
+    out["alu_busy"] = {
+        "mfma_insts_per_launch": mfma, "mfma_busy_cycles_per_launch": busy, "mfma_valu_coexec_cycles_per_launch": coexec,
+        "kernel_cycles": round(cyc), "valu_cycles_per_simd": round((out["valu_insts_per_launch"] - mfma) * 2.7 / 1024),
+        "mfma_cycles_per_simd": round(busy / 1024),
+        "frac": round(((out["valu_insts_per_launch"] - mfma) * 2.7 + busy) / 1024 / cyc, 3),
+        "definition": "((vector instructions - matrix instructions) x 2.7 cycles + SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs / "
+                      "(GRBM_GUI_ACTIVE / 8): share of the kernel's cycles in which a SIMD's vector / matrix pipe is taken; "
+                      "SQ_VALU_MFMA_COEXEC_CYCLES (cycles with both kinds in flight) is reported, not subtracted: "
+                      "tools/microbench_mfma2.hip shows the two adding up on one SIMD",
+    }
+except Exception as e:  # (older pmc.txt without the matrix-pipe pass)
+    print("no alu_busy:", e)
 json.dump(out, open(os.path.join(dst, "pmc_occlusion.json"), "w"), indent=2)
 print(json.dumps(out, indent=1))
 
@@ -59,6 +81,7 @@ if os.path.exists(pu):
             "workload": "bench.py --workload uniform1m (1 000 000 atoms in one structure, 960 points)",
             "source": "rocprofv3 --pmc SQ_INSTS_* (tools/profile_round.sh, profiles/" + prefix + "_pmc_uniform1m.txt)",
             "valu_insts_per_launch": vu("SQ_INSTS_VALU"), "mfma_insts_per_launch": vu("SQ_INSTS_MFMA"),
-            "salu_insts_per_launch": vu("SQ_INSTS_SALU"), "lds_insts_per_launch": vu("SQ_INSTS_LDS")}
+            "salu_insts_per_launch": vu("SQ_INSTS_SALU"), "lds_insts_per_launch": vu("SQ_INSTS_LDS"),
+            "kernel_source_sha16": bench.kernel_source_hash()}
     json.dump(outu, open(os.path.join(dst, "pmc_uniform1m.json"), "w"), indent=2)
     print(json.dumps(outu, indent=1))
