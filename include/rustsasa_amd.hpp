@@ -18,11 +18,18 @@
 //     to span every model; if they do, the reference sums an ensemble's models
 //     into one result where this library reports model 1.  Single-model files
 //     (every fixture of the reference's tests, every AlphaFold model) are
-//     unaffected;
-//   * a residue's first conformer (`conformers().next()`, src/options.rs:162,255)
-//     is the first (residue name, alt-loc) pair met in file order: checked
-//     against the reference's own quality gate on alt-loc files
-//     (tests/test_host_api.py, fixtures tests/golden/data/freesasa/).
+//     unaffected (pinned by tests/test_host_api.py::test_first_model_only_is_pinned);
+//   * conformers: one per (residue name, alt-loc) pair in file order; in a residue
+//     with alternate locations the atoms WITHOUT one belong to every conformer
+//     (appended after the conformer's own atoms) and the blank conformer goes, so
+//     that a residue's first conformer (`conformers().next()`,
+//     src/options.rs:162,255) is backbone + first alternate location.  With this
+//     rule the reference's whole quality set (88 files, 71 with alternate
+//     locations; tools/check_quality_set.py) gives an RMSE of 43.997 against
+//     FreeSASA - the reference's own figure is 43.99 (tests/quality.rs:17); with
+//     blank and lettered conformers kept apart it is 142.  The ORDER of atoms
+//     inside such a conformer (it decides AtomLevel's order and the f32 order of
+//     ResidueLevel's sums on those residues) remains this library's choice.
 #pragma once
 
 #include <cstdint>
@@ -165,7 +172,19 @@ struct FilesTimings {
     std::size_t n_files = 0, n_atoms = 0;
 };
 
+// What ChainLevel hands to the hot path for one structure: the kept atoms (build_atoms_and_mapping,
+// options.rs:317-364: first conformer per residue, hydrogen / HETATM filters, radii by options) and, per chain
+// in file order, its id and the end of its atoms.  No GPU involved: used to check the selection against the
+// reference's quality set (tools/check_quality_set.py).
+struct SelectedAtoms {
+    std::vector<rsasa_atom_t> atoms;
+    std::vector<std::string> chain_ids;
+    std::vector<std::uint32_t> chain_end;
+};
+Result<SelectedAtoms> select_atoms_by_chain(const Structure &pdb, const OptionValues &o);
+
 namespace detail {
+Result<SelectedAtoms> select_by_chain(const Structure &pdb, const OptionValues &o);
 Result<std::vector<float>> run_hot_path(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms);
 template <typename Level>
 std::vector<Result<typename Level::Output>> process_many(const std::vector<const Structure *> &pdbs,

@@ -348,6 +348,27 @@ inline void set_element(AtomRecord &rec, const TextView &symbol)
     if (rec.element.empty()) rec.element = element_from_name(rec.name);
 }
 
+// Atoms without an alternate location belong to EVERY conformer of a residue that has alternate locations
+// (a side chain modelled twice on one backbone): the blank conformer's atoms are appended to each of the
+// others and the blank conformer goes.  The reference's `residue.conformers().next()` (src/options.rs:162,255)
+// then selects backbone + first alternate location, which is what its quality gate over the FreeSASA set
+// (tests/quality.rs:17-18, RMSE 43.99 of the reference itself) implies for pdbtbx - whose source is not in
+// the reference tree, so the order inside a conformer (its own atoms, then the shared ones) is our choice.
+inline void share_blank_conformers(Structure &s)
+{
+    for (Chain &chain : s.chains)
+        for (Residue &res : chain.residues) {
+            if (res.conformers.size() < 2) continue;
+            size_t blank = res.conformers.size();
+            for (size_t k = 0; k < res.conformers.size(); k++)
+                if (res.conformers[k].alt_loc.empty()) { blank = k; break; }
+            if (blank == res.conformers.size()) continue;
+            const Conformer shared = std::move(res.conformers[blank]);
+            res.conformers.erase(res.conformers.begin() + (std::ptrdiff_t)blank);
+            for (Conformer &c : res.conformers) c.atoms.insert(c.atoms.end(), shared.atoms.begin(), shared.atoms.end());
+        }
+}
+
 // the next line of `text` from `cur` (advanced past it), without its line end
 inline LineView next_line(const char *&cur, const char *end)
 {
@@ -395,6 +416,7 @@ Structure Structure::from_pdb_text(const std::string &text)
         rec.b_factor = column_decimal(line, 61, 66, 0.0);
         set_element(rec, field_view(line, 77, 78));
     }
+    share_blank_conformers(s);
     return s;
 }
 
@@ -522,6 +544,7 @@ Structure Structure::from_mmcif_text(const std::string &text)
         rec.b_factor = num(c_b, 0.0);
         set_element(rec, val(c_sym));
     }
+    share_blank_conformers(s);
     return s;
 }
 
@@ -876,6 +899,26 @@ Prepared prepare<ProteinLevel>(const Structure &pdb, const OptionValues &o)
     return p;
 }
 
+}  // namespace
+
+// (public, see the header) the ChainLevel selection of one structure without any GPU work
+Result<SelectedAtoms> select_by_chain(const Structure &pdb, const OptionValues &o)
+{
+    Result<SelectedAtoms> r;
+    Prepared p = prepare<ChainLevel>(pdb, o);
+    if (p.err.error != SASACalcError::Ok) {
+        r.error = p.err.error;
+        r.message = p.err.message;
+        return r;
+    }
+    r.value.atoms = std::move(p.atoms);
+    r.value.chain_end = std::move(p.seg_end);
+    for (const Chain &c : pdb.chains) r.value.chain_ids.push_back(c.id);
+    return r;
+}
+
+namespace {
+
 // process_atoms of each level (options.rs:142-149, 195-232, 292-315, 370-410).  `atom` and
 // `seg` are this structure's slices of the batch results; `global` is the sequential f32 sum
 // over all its atoms (used by ProteinLevel only).
@@ -1200,6 +1243,11 @@ RSASA_INSTANTIATE(ProteinLevel)
 #undef RSASA_INSTANTIATE
 
 }  // namespace detail
+
+Result<SelectedAtoms> select_atoms_by_chain(const Structure &pdb, const OptionValues &o)
+{
+    return detail::select_by_chain(pdb, o);
+}
 
 template <typename Level>
 Result<typename Level::Output> SASAOptions<Level>::process(const Structure &pdb) const

@@ -201,6 +201,25 @@ int main(int argc, char **argv)
             auto r = make<ProteinLevel>(argc, argv).process(pdb);
             if (!r.ok()) return fail(r);
             return emit(r.value);
+        } else if (level == "select") {
+            // reader + atom selection + radii, no GPU: what ChainLevel would hand to the hot path, one atom per
+            // line (x y z radius as hex floats, id, chain index), preceded by the chains' ids
+            auto r = select_atoms_by_chain(pdb, make<ChainLevel>(argc, argv).values());
+            if (!r.ok()) return fail(r);
+            std::printf("{\"chains\":[");
+            for (size_t c = 0; c < r.value.chain_ids.size(); c++) {
+                std::printf("%s", c ? "," : "");
+                print_str(r.value.chain_ids[c]);
+            }
+            std::printf("],\"chain_end\":[");
+            for (size_t c = 0; c < r.value.chain_end.size(); c++) std::printf("%s%u", c ? "," : "", r.value.chain_end[c]);
+            std::printf("],\"atoms\":[");
+            for (size_t i = 0; i < r.value.atoms.size(); i++) {
+                const rsasa_atom_t &a = r.value.atoms[i];
+                std::printf("%s[%.9g,%.9g,%.9g,%.9g,\"%llu\"]", i ? "," : "", a.position[0], a.position[1], a.position[2],
+                            a.radius, (unsigned long long)a.id);
+            }
+            std::printf("]}\n");
         } else if (level == "rewrite") {  // reader -> writer round trip, no GPU
             std::printf("%s", pdb.to_pdb_text().c_str());
         } else if (level == "parse") {  // reader only (no GPU): atom / residue / chain counts

@@ -16,7 +16,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 DATA_DIR = os.path.join(GOLDEN_DIR, "data")
 
 # pdbtbx element van-der-Waals radii used by the reference's tests/units.rs:18-33
-VDW = {"H": 1.20, "C": 1.77, "N": 1.66, "O": 1.50, "S": 1.89, "P": 1.90, "SE": 1.82}
+VDW = {"H": 1.20, "C": 1.77, "N": 1.66, "O": 1.50, "S": 1.89, "P": 1.90, "SE": 1.82, "CL": 1.82, "ZN": 2.39, "D": 1.20}
 
 
 @dataclass
@@ -107,6 +107,27 @@ def read_mmcif(path):
 
 def read_structure(path):
     return read_mmcif(path) if path.endswith(".cif") else read_pdb(path)
+
+
+def conformers(residue_atoms):
+    """The conformers of one residue as the reference's model holds them (pdbtbx): one per (residue name,
+    alternate location) in order of first appearance; in a residue with alternate locations the atoms WITHOUT
+    one belong to every conformer (appended after the conformer's own), and the blank conformer goes.
+    Returns [(name, altloc, [atoms])]."""
+    order, groups = [], {}
+    for a in residue_atoms:
+        key = (a.resname, a.altloc)
+        if key not in groups:
+            groups[key] = []
+            order.append(key)
+        groups[key].append(a)
+    if len(order) > 1:
+        blank = next((k for k in order if k[1] == ""), None)
+        if blank is not None:
+            order.remove(blank)
+            for k in order:
+                groups[k] = groups[k] + groups[blank]
+    return [(k[0], k[1], groups[k]) for k in order]
 
 
 def data_path(name):

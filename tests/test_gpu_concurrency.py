@@ -74,3 +74,60 @@ def test_context_churn_leaves_results_stable():
                 assert np.array_equal(got, want)
             else:
                 assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, 8))
+
+
+def test_two_batches_in_flight_in_one_context():
+    """rsasa_batch_enqueue keeps up to two batches in flight per context (two workspaces, two streams; a third
+    enqueue first waits for the oldest); rsasa_batch_wait returns them oldest first.  Different batches, different
+    point counts and batches small enough for the per-atom kernels, interleaved: every result equals the
+    one-batch-at-a-time run, and a wait with nothing in flight returns at once."""
+    import torch
+    import rustsasa_amd
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    batches = [bw.synthetic_proteome(60, seed=3), bw.synthetic_proteome(25, seed=4), bw.synthetic_proteome(3, seed=5),
+               bw.synthetic_proteome(40, seed=6)]
+    points = [100, 96, 100, 1000]
+    with rustsasa_amd.Context(0) as ctx:
+        ctx.wait()  # nothing in flight
+        dev_in, want = [], []
+        for b, n_points in zip(batches, points):
+            x, y, z, r, ids = t(b.x), t(b.y), t(b.z), t(b.radius), t(b.ids.view(np.int64))
+            ro = t(b.residue_offsets.view(np.int32))
+            dev_in.append((x, y, z, r, ids, ro))
+            out = torch.empty(b.n_atoms, dtype=torch.float32, device=dev)
+            res = torch.empty(b.n_residues, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            ctx.enqueue_device(x, y, z, r, ids, b.structure_offsets, out, ro, res, None, 1.4, n_points)
+            ctx.wait()
+            want.append((out.cpu().numpy(), res.cpu().numpy()))
+        # all four enqueued back to back (the third and fourth enqueue wait for the first and second themselves),
+        # twice over, results collected oldest first
+        for _ in range(2):
+            outs = []
+            for (x, y, z, r, ids, ro), b, n_points in zip(dev_in, batches, points):
+                out = torch.full((b.n_atoms,), -1.0, dtype=torch.float32, device=dev)
+                res = torch.full((b.n_residues,), -1.0, dtype=torch.float32, device=dev)
+                outs.append((out, res))
+                torch.cuda.synchronize()
+                ctx.enqueue_device(x, y, z, r, ids, b.structure_offsets, out, ro, res, None, 1.4, n_points)
+            ctx.wait_all()
+            ctx.wait()
+            for (out, res), (wa, wr) in zip(outs, want):
+                assert np.array_equal(out.cpu().numpy(), wa) and np.array_equal(res.cpu().numpy(), wr)
+        # enqueue k + 1, then wait for k
+        x, y, z, r, ids, ro = dev_in[0]
+        b = batches[0]
+        o = [(torch.empty(b.n_atoms, dtype=torch.float32, device=dev), torch.empty(b.n_residues, dtype=torch.float32, device=dev))
+             for _ in range(2)]
+        ctx.enqueue_device(x, y, z, r, ids, b.structure_offsets, o[0][0], ro, o[0][1], None, 1.4, 100)
+        for i in range(1, 7):
+            ctx.enqueue_device(x, y, z, r, ids, b.structure_offsets, o[i % 2][0], ro, o[i % 2][1], None, 1.4, 100)
+            ctx.wait()
+            assert np.array_equal(o[(i - 1) % 2][0].cpu().numpy(), want[0][0])
+            o[(i - 1) % 2][0].fill_(-1.0)
+        ctx.wait()
+        assert np.array_equal(o[0][0].cpu().numpy(), want[0][0]) and np.array_equal(o[0][1].cpu().numpy(), want[0][1])
+    # the oracle on one of the batches, so that "equal" is not equally wrong
+    b = batches[2]
+    assert np.array_equal(want[2][0], po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, 1.4, 100, 8, threads=4))

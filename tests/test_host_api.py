@@ -53,24 +53,34 @@ def residues_in_order(atoms):
     return out
 
 
-def expected(name, n_points=100, include_hetatms=False, vdw_fallback=False):
-    atoms = sio.read_structure(sio.data_path(name))
+def n_model_atoms(atoms):
+    """Atoms of the model the reader builds: atoms without an alternate location count once per conformer of a
+    residue that has alternate locations (structio.conformers)."""
+    return sum(len(c[2]) for _, _, ratoms in residues_in_order(atoms) for c in sio.conformers(ratoms))
+
+
+def expected(name, n_points=100, include_hetatms=False, vdw_fallback=False, include_hydrogens=False,
+             radii_from_occupancy=False, radii_table=None, path=None):
+    atoms = sio.read_structure(path or sio.data_path(name))
     tab = sio.parse_protor(sio.data_path("protor.config"))
     sel, res_offsets, res_meta, chain_of_res = [], [0], [], []
     for chain, (resseq, icode), ratoms in residues_in_order(atoms):
-        first_conf = (ratoms[0].resname, ratoms[0].altloc)
-        for a in ratoms:
-            if (a.resname, a.altloc) != first_conf:
+        conf_name, _, conf_atoms = sio.conformers(ratoms)[0]  # `residue.conformers().next()`, options.rs:162,255
+        for a in conf_atoms:
+            if (a.element == "H" and not include_hydrogens) or (a.hetero and not include_hetatms):
                 continue
-            if a.element == "H" or (a.hetero and not include_hetatms):
-                continue
-            r = tab.get((a.resname, a.name))
-            if r is None:
-                assert vdw_fallback, (a.resname, a.name)
-                r = sio.VDW[a.element]
+            if radii_from_occupancy:
+                r = a.occupancy                                  # options.rs:83-84
+            else:
+                r = (radii_table or {}).get((a.resname, a.name))  # utils.rs:45-53: the custom table first
+                if r is None:
+                    r = tab.get((a.resname, a.name))
+                if r is None:
+                    assert vdw_fallback, (a.resname, a.name)
+                    r = sio.VDW[a.element]
             sel.append((a, r))
         res_offsets.append(len(sel))
-        res_meta.append((resseq, icode, ratoms[0].resname, chain))
+        res_meta.append((resseq, icode, conf_name, chain))
     x = np.array([a.x for a, _ in sel], np.float64).astype(np.float32)
     y = np.array([a.y for a, _ in sel], np.float64).astype(np.float32)
     z = np.array([a.z for a, _ in sel], np.float64).astype(np.float32)
@@ -85,7 +95,7 @@ def expected(name, n_points=100, include_hetatms=False, vdw_fallback=False):
 def test_reader_counts_match_independent_parser(name):
     atoms = sio.read_structure(sio.data_path(name))
     got = run_cli("parse", name)
-    assert got["atoms"] == len(atoms)
+    assert got["atoms"] == n_model_atoms(atoms)
     assert got["chains"] == len({a.chain for a in atoms})
     assert got["residues"] == len({(a.chain, a.resseq, a.icode) for a in atoms})
 
@@ -335,7 +345,7 @@ def test_altloc_reader_counts_match_independent_parser(pid):
     assert _altloc_count(name) > 0          # the fixture really exercises alternate locations
     atoms = sio.read_structure(sio.data_path(name))
     got = run_cli("parse", name)
-    assert got["atoms"] == len(atoms)
+    assert got["atoms"] == n_model_atoms(atoms) >= len(atoms)  # (shared atoms count once per conformer)
     assert got["chains"] == len({a.chain for a in atoms})
     assert got["residues"] == len({(a.chain, a.resseq, a.icode) for a in atoms})
 
@@ -344,7 +354,9 @@ def test_altloc_reader_counts_match_independent_parser(pid):
 @pytest.mark.parametrize("pid", ALTLOC)
 def test_first_conformer_selection_on_altloc_files(pid):
     """A residue contributes its FIRST conformer only (reference src/options.rs:162,255:
-    `residue.conformers().next()`): here the first (residue name, alt-loc) pair met in file order.
+    `residue.conformers().next()`): the first (residue name, alt-loc) pair met in file order, plus - in a
+    residue with alternate locations - the atoms without one, which belong to every conformer (this is what
+    reproduces the reference's own RMSE of 43.99 on its whole FreeSASA set: tools/check_quality_set.py).
     The C++ reader must select exactly the atoms the independent Python reader selects, give them
     the same radii, and do so deterministically."""
     name = f"freesasa/{pid}.pdb"
@@ -377,3 +389,165 @@ def test_altloc_files_meet_the_reference_quality_gate():
     rmse = float(np.sqrt(np.mean((np.array(ours) - np.array(theirs)) ** 2)))
     assert len(ours) >= len(ALTLOC)
     assert rmse <= RMSE_GATE, rmse
+
+
+# ---- host options the reference tests and the reader semantics behind them ---------------------------------
+# (tests/quality.rs:340-442 radii from occupancy; src/utils/consts.rs:31-81 + src/utils.rs:40-56 custom radii
+# file; src/options.rs:166 hydrogens: 12 of the reference's 88 quality files carry them, here 4c1a)
+
+def _with_radii_in_occupancy(src, dst):
+    """tests/quality.rs:262-334: every atom's occupancy becomes its ProtOr radius (vdW radius where the table has none)."""
+    tab = sio.parse_protor(sio.data_path("protor.config"))
+    out = []
+    for line in open(src):
+        if line.startswith(("ATOM", "HETATM")):
+            r = tab.get((line[17:20].strip(), line[12:16].strip()))
+            if r is None:
+                r = sio.VDW.get(line[76:78].strip().upper(), 2.0)
+            line = line[:54] + f"{r:6.2f}" + line[60:]
+        out.append(line)
+    open(dst, "w").write("".join(out))
+
+
+RADII_FILE = """name: custom
+types:
+BIGC 2.25 apolar
+SMALLO 1.25 polar
+atoms:
+ALA CB BIGC
+GLY O SMALLO
+LEU CD1 BIGC
+XYZ Q BIGC
+"""
+
+
+def _select(path, *opts):
+    p = subprocess.run([CLI, "select", path, *opts], capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[:300], p.stderr[:300])
+    d = json.loads(p.stdout)
+    a = d["atoms"]
+    cols = [np.array([v[k] for v in a], np.float32) for k in range(4)]
+    ids = np.array([int(v[4]) for v in a], np.uint64)
+    return cols, ids, d
+
+
+def _expected_selection(path, **kw):
+    atoms = sio.read_structure(path)
+    tab = sio.parse_protor(sio.data_path("protor.config"))
+    sel = []
+    for chain, _, ratoms in residues_in_order(atoms):
+        for a in sio.conformers(ratoms)[0][2]:
+            if (a.element == "H" and not kw.get("include_hydrogens")) or (a.hetero and not kw.get("include_hetatms")):
+                continue
+            if kw.get("radii_from_occupancy"):
+                r = a.occupancy
+            else:
+                r = (kw.get("radii_table") or {}).get((a.resname, a.name))
+                if r is None:
+                    r = tab.get((a.resname, a.name))
+                if r is None:
+                    r = sio.VDW[a.element]
+            sel.append((a, r, chain))
+    return sel
+
+
+OPTION_CASES = [
+    ("freesasa/4c1a.pdb", ["--include-hydrogens", "--allow-vdw-fallback"], dict(include_hydrogens=True)),
+    ("freesasa/4c1a.pdb", [], {}),
+    ("freesasa/3kyz.pdb", ["--include-hetatms", "--allow-vdw-fallback"], dict(include_hetatms=True)),
+    ("1jcd.pdb", ["--read-radii-from-occupancy"], dict(radii_from_occupancy=True)),
+    ("freesasa/2gpi.pdb", ["--read-radii-from-occupancy"], dict(radii_from_occupancy=True)),
+    ("1jcd.pdb", ["--radii-file"], dict(radii_table=True)),
+    ("example.cif", ["--radii-file"], dict(radii_table=True)),
+]
+
+
+def _case(tmp_path, name, opts, kw):
+    path = sio.data_path(name)
+    kw = dict(kw)
+    opts = list(opts)
+    if kw.get("radii_from_occupancy"):
+        dst = str(tmp_path / os.path.basename(name))
+        _with_radii_in_occupancy(path, dst)
+        path = dst
+    if kw.get("radii_table"):
+        cfg = tmp_path / "custom.config"
+        cfg.write_text(RADII_FILE)
+        opts.append(str(cfg))
+        kw["radii_table"] = {("ALA", "CB"): 2.25, ("GLY", "O"): 1.25, ("LEU", "CD1"): 2.25}
+    return path, opts, kw
+
+
+@pytest.mark.parametrize("name,opts,kw", OPTION_CASES)
+def test_selection_under_reference_tested_options(tmp_path, name, opts, kw):
+    """No GPU: the atoms, radii and chains the C++ host API hands to the hot path (`sasa_host_cli select`)
+    against the independent Python reader, for the options the reference's own tests exercise."""
+    path, opts, kw = _case(tmp_path, name, opts, kw)
+    (x, y, z, r), ids, d = _select(path, *opts)
+    want = _expected_selection(path, **kw)
+    assert len(x) == len(want) > 0
+    assert np.array_equal(x, np.array([a.x for a, _, _ in want], np.float64).astype(np.float32))
+    assert np.array_equal(y, np.array([a.y for a, _, _ in want], np.float64).astype(np.float32))
+    assert np.array_equal(z, np.array([a.z for a, _, _ in want], np.float64).astype(np.float32))
+    assert np.array_equal(r, np.array([rr for _, rr, _ in want], np.float64).astype(np.float32))
+    if kw.get("include_hydrogens"):
+        assert any(a.element == "H" for a, _, _ in want)
+    if kw.get("radii_table"):
+        assert np.any(r == np.float32(2.25))
+    # chains: ids in file order, contiguous ranges
+    chains = []
+    for _, _, c in want:
+        if not chains or chains[-1][0] != c:
+            chains.append([c, 0])
+        chains[-1][1] += 1
+    assert [c for c, _ in chains] == [c for c, e, b in zip(d["chains"], d["chain_end"], [0] + d["chain_end"]) if e > b]
+    assert len(set(ids.tolist())) == len(ids)  # FNV(alt-loc, serial): distinct atoms, distinct ids
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,opts,kw", OPTION_CASES)
+def test_levels_under_reference_tested_options(tmp_path, name, opts, kw):
+    """The same cases through the GPU: AtomLevel and ResidueLevel values equal the oracle's on the Python
+    reader's selection."""
+    path, opts, kw = _case(tmp_path, name, opts, kw)
+    atom, res, meta = expected(name, vdw_fallback=True, path=path, **kw)
+    p = subprocess.run([CLI, "atom", path, *opts], capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[:300], p.stderr[:300])
+    got = np.array(json.loads(p.stdout)["Atom"], np.float32)
+    assert np.array_equal(got, atom)
+    p = subprocess.run([CLI, "residue", path, *opts], capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[:300], p.stderr[:300])
+    got_res = json.loads(p.stdout)["Residue"]
+    assert np.array_equal(np.array([g["value"] for g in got_res], np.float32), res)
+
+
+def test_first_model_only_is_pinned(tmp_path):
+    """A file with several MODELs: this reader keeps the FIRST model (documented in include/rustsasa_amd.hpp and
+    DESIGN.md; pdbtbx, whose source is not in the reference tree, appears to iterate over every model's chains,
+    which would overlay all models in one computation).  Pinned here so that a change is a decision."""
+    src = open(sio.data_path("1jcd.pdb")).read().splitlines(keepends=True)
+    body = [l for l in src if l.startswith(("ATOM", "HETATM", "TER"))]
+    shifted = [l[:30] + f"{float(l[30:38]) + 50.0:8.3f}" + l[38:] if l.startswith(("ATOM", "HETATM")) else l for l in body]
+    two = tmp_path / "two_models.pdb"
+    two.write_text("MODEL        1\n" + "".join(body) + "ENDMDL\nMODEL        2\n" + "".join(shifted) + "ENDMDL\nEND\n")
+    (x2, y2, z2, r2), ids2, d2 = _select(str(two))
+    (x1, y1, z1, r1), ids1, d1 = _select(sio.data_path("1jcd.pdb"))
+    assert np.array_equal(x1, x2) and np.array_equal(r1, r2) and d1["chain_end"] == d2["chain_end"]
+
+
+def test_altloc_fixtures_meet_the_quality_gate_without_a_gpu():
+    """tests/quality.rs:225 on the committed alt-loc fixtures through `select` + oracle (the whole set of 88:
+    tools/check_quality_set.py in the build container, RMSE 43.997 - the reference's own 43.99)."""
+    ours, theirs = [], []
+    for pid in ALTLOC + ["4c1a"]:
+        (x, y, z, r), ids, d = _select(sio.data_path(f"freesasa/{pid}.pdb"))
+        atom = po.calculate_sasa_internal(x, y, z, r, ids, 1.4, 100, 8, threads=0)
+        sums = po.residue_sums(atom, np.array([0] + d["chain_end"], np.uint32))
+        got = dict(zip(d["chains"], (float(v) for v in sums)))
+        ref = json.load(open(sio.data_path(f"freesasa/{pid}.json")))
+        want = {c["label"]: c["area"]["total"] for rr in ref["results"] for s in rr["structure"] for c in s["chains"]}
+        for k in sorted(set(want) & set(got)):
+            ours.append(got[k])
+            theirs.append(want[k])
+    rmse = float(np.sqrt(np.mean((np.array(ours) - np.array(theirs)) ** 2)))
+    assert len(ours) >= 7 and rmse <= RMSE_GATE, rmse
