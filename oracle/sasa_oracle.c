@@ -3,7 +3,7 @@
  *
  * TEST INFRASTRUCTURE ONLY (see sasa_oracle.h).  Parity status: PINNED against
  * the reference's golden vector FIXED_LOW_RES_ATOMS and its analytic tests;
- * see tests/test_oracle_golden.py.
+ * see tests/test_oracle.py.
  *
  * Build: gcc -O3 -march=x86-64-v3 -ffp-contract=off -fopenmp (oracle/Makefile).
  * Contraction is OFF so that the only fused operations are the explicit

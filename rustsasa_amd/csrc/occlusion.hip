@@ -1,10 +1,12 @@
 // Occlusion kernels of the MI355X-native Shrake-Rupley engine (gfx950 only).
 //
-// One wavefront per atom, atoms taken in cell-sorted order (a workgroup's four
-// waves work on spatial neighbours, and the XCD-aware remap gives every XCD a
-// contiguous range of structures so its L2 holds only those).  Three kernels make the same
-// decisions:
-//   k_occlusion_fast (occlusion_fast.inc)  the straight-line kernel for the common case
+// Atoms are taken in cell-sorted order (a workgroup's waves work on spatial neighbours, and the
+// XCD-aware remap gives every XCD a contiguous range of structures so its L2 holds only those).
+// Four kernels make the same decisions:
+//   k_occlusion_mx (occlusion_mx.inc)      batches of 32 768 atoms or more: 64 atoms per wave, a group
+//       of neighbouring atoms shares one union of swept atoms in registers, point tests on the matrix
+//       instructions (f16 filter, exact f32); atoms it cannot take go to the batch's deferred list;
+//   k_occlusion_fast (occlusion_fast.inc)  smaller batches, one wavefront per atom: the straight-line kernel for the common case
 //       (n_points <= 128, <= 4 remainder points); atoms it cannot take (more than 256 atoms in
 //       the culled runs, more than 144 candidates) go to the batch's deferred list;
 //   k_occlusion_v3 (occlusion_v3.inc)      the general kernel: any n_points (groups of two
@@ -13,7 +15,7 @@
 //   k_occlusion_v0 (occlusion_v0.inc)      all candidates x all points, no culling: an
 //       independent implementation for A/B checks (RSASA_OCCLUSION_KERNEL=0).
 //
-// Stages (details differ between fast and v3, see the files):
+// Stages of the per-atom kernels (details differ between fast and v3, see the files; k_occlusion_mx: its own file):
 //   PROLOGUE (per wave, a group of its atoms at once, 64 (atom, run) pairs per pass): the 25
 //      x-runs of cells of the 5x5x5 block around each atom's cell (search_extent = 2, reference
 //      spatial_grid.rs:47: max_search / cell_size is exactly 2 in f32), culled and trimmed with
@@ -177,10 +179,13 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         else hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
         return;
     }
-    if (tune.debug_stop != 0) {  // timing ablation build (tools/ablate.sh); results are wrong
+#ifdef RSASA_ABLATE  // timing ablation build (make ablate, tools/ablate.sh): results are wrong; not in the shipped library
+    if (tune.debug_stop != 0) {
         if (b.id) hipLaunchKernelGGL((k_occlusion_v3<2, true, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
         else hipLaunchKernelGGL((k_occlusion_v3<2, false, true>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
-    } else if (b.id) {
+    } else
+#endif
+    if (b.id) {
         hipLaunchKernelGGL((k_occlusion_v3<2, true, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
     } else {
         hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(a.n_blocks), dim3(256), 0, stream, a3);
