@@ -64,6 +64,8 @@ int rsasa_device_count(int *out_count);
 int rsasa_context_create(int device, rsasa_context_t **out_ctx);
 int rsasa_context_destroy(rsasa_context_t *ctx);
 const char *rsasa_context_last_error(const rsasa_context_t *ctx);
+/* The GPU index the context was created on (directory mode opens its second worker context there). */
+int rsasa_context_get_device(const rsasa_context_t *ctx, int *out_device);
 
 /* pulp lane count W the reference host would dispatch to (8 = AVX2+FMA
  * [default], 16 = AVX-512, 4 = NEON, 1 = scalar).  It only selects which of

@@ -66,6 +66,7 @@ SYMBOLS = {
     "rsasa_context_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "rsasa_context_destroy": (C.c_int, [_vp]),
     "rsasa_context_last_error": (C.c_char_p, [_vp]),
+    "rsasa_context_get_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "rsasa_context_set_simd_width": (C.c_int, [_vp, C.c_int]),
     "rsasa_calculate_sasa_internal": (C.c_int, [_vp, _vp, C.c_size_t, C.c_float, C.c_size_t,
                                                 C.c_ssize_t, _vp]),

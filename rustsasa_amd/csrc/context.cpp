@@ -738,6 +738,13 @@ const char *rsasa_context_last_error(const rsasa_context_t *ctx)
     return copy.c_str();
 }
 
+int rsasa_context_get_device(const rsasa_context_t *ctx, int *out_device)
+{
+    if (!ctx || !out_device) return RSASA_ERR_INVALID_ARGUMENT;
+    *out_device = ctx->device;
+    return RSASA_OK;
+}
+
 int rsasa_context_set_simd_width(rsasa_context_t *ctx, int w)
 {
     int rc = resolve_ctx(ctx);

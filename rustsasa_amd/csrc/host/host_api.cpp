@@ -17,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <malloc.h>
+#include <sys/stat.h>
 #include <sstream>
 #include <stdexcept>
 #include <thread>
@@ -1130,12 +1131,23 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // parsing is allocation heavy and stops scaling early (measured: 32 threads are the optimum on a
     // 256-thread host, 64 are slower), so the default is capped
     if (host_threads == 0) host_threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-    if (files_per_batch == 0) files_per_batch = 256;
-    // one worker per given context; with a single context two workers share it (calls on a context
-    // are serialised, but packing, result building and freeing of two chunks then overlap)
+    // (chunks of 512 files and two GPU workers: 16.4 k files/s on the 4 363-file set against 13.3 k with 256 and one
+    // shared context - fewer per-chunk joins of the parse pool, and one chunk's upload beside the other's kernels)
+    if (files_per_batch == 0) files_per_batch = 512;
+    // one worker per given context; with a single context a second, private one on the same device joins it
+    // for the duration of the call (calls on one context are serialised)
     std::vector<rsasa_context_t *> contexts = o.contexts;
     if (contexts.empty()) contexts.push_back(o.context);
-    if (contexts.size() == 1) contexts.push_back(contexts[0]);
+    struct Borrowed {
+        rsasa_context_t *ctx = nullptr;
+        ~Borrowed() { if (ctx) rsasa_context_destroy(ctx); }
+    } second;
+    if (contexts.size() == 1 && paths.size() > files_per_batch) {
+        int device = 0;
+        if (contexts[0] && rsasa_context_get_device(contexts[0], &device) != RSASA_OK) device = 0;
+        if (rsasa_context_create(device, &second.ctx) == RSASA_OK) contexts.push_back(second.ctx);
+        else contexts.push_back(contexts[0]);  // (no second context: two workers share the one, as before)
+    }
 
     struct Chunk {
         size_t base = 0, n = 0;
@@ -1196,7 +1208,15 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
         c->pdbs.resize(c->n);
         c->prep.resize(c->n);
         const auto t0 = Clock::now();
-        parallel_for(c->n, host_threads, [&](size_t i) {
+        // largest files first: the chunk's parse ends with the pool, not with one thread on a 2 MB file
+        std::vector<std::pair<uint64_t, size_t>> order(c->n);
+        for (size_t i = 0; i < c->n; i++) {
+            struct stat st{};
+            order[i] = {::stat(paths[base + i].c_str(), &st) == 0 ? (uint64_t)st.st_size : 0u, i};
+        }
+        std::sort(order.begin(), order.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+        parallel_for(c->n, host_threads, [&](size_t k) {
+            const size_t i = order[k].second;
             try {
                 c->pdbs[i] = Structure::open(paths[base + i]);
                 c->prep[i] = prepare<Level>(c->pdbs[i], o);
