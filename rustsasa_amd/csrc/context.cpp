@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -64,7 +66,36 @@ struct Pending {
     int attempts = 0;
     const uint32_t *id32 = nullptr;  // nullable (pipelined host path): the ids folded by the host; batch.id is then a
                                      // device-accessible pointer the general kernel alone reads (BatchView::id32)
+    const uint8_t *radius8 = nullptr;     // nullable (pipelined host path): one-byte radius codes + their table
+    const float *radius_table = nullptr;  // (BatchView::radius8); batch.radius is then not read
     int ws = 0;                      // the workspace (and host slot) the batch runs in
+};
+
+// The distinct radii of a host batch, collected while worker threads turn the radii into one-byte codes: a
+// structure file has a dozen distinct radii, so 1 byte per atom crosses the link instead of 4.  More than 256
+// distinct values: `failed`, and the f32 radii are uploaded as before.
+struct RadiusCodec {
+    float table[256];
+    std::atomic<int> n{0};
+    std::atomic<bool> failed{false};
+    std::mutex mu;
+    void reset() { n.store(0); failed.store(false); }
+    static uint32_t bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+    int code(float value)  // the value's code (compared by bit pattern: -0.0, NaN payloads survive), or -1
+    {
+        const uint32_t b = bits(value);
+        int cnt = n.load(std::memory_order_acquire);
+        for (int k = 0; k < cnt; k++)
+            if (bits(table[k]) == b) return k;
+        std::lock_guard<std::mutex> lk(mu);
+        const int now = n.load(std::memory_order_relaxed);
+        for (int k = cnt; k < now; k++)
+            if (bits(table[k]) == b) return k;
+        if (now == 256) { failed.store(true); return -1; }
+        table[now] = value;
+        n.store(now + 1, std::memory_order_release);
+        return now;
+    }
 };
 
 // A few worker threads that fold 64-bit ids to 32 bits (device_utils.h fold_id) ahead of the uploads: the
@@ -85,11 +116,13 @@ public:
         cv.notify_all();
         for (auto &w : workers) w.join();
     }
-    // queues folding src[0 .. n) into dst; returns the job's number for wait()
-    unsigned long long submit(const uint64_t *src, uint32_t *dst, size_t n)
+    // queues folding src[0 .. n) into dst (either may be null) and coding rad[0 .. n) into rad8 (if codec is set);
+    // returns the job's number for wait()
+    unsigned long long submit(const uint64_t *src, uint32_t *dst, size_t n, const float *rad = nullptr, uint8_t *rad8 = nullptr,
+                              RadiusCodec *codec = nullptr)
     {
         std::lock_guard<std::mutex> lk(mu);
-        jobs.push_back(Job{src, dst, n, 0, 0});
+        jobs.push_back(Job{src, dst, n, 0, 0, rad, rad8, codec});
         cv.notify_all();
         return first_job + jobs.size() - 1;
     }
@@ -105,6 +138,9 @@ private:
         const uint64_t *src;
         uint32_t *dst;
         size_t n, next, finished;  // next block to hand out, blocks finished
+        const float *rad;
+        uint8_t *rad8;
+        RadiusCodec *codec;
     };
     void run()
     {
@@ -116,9 +152,26 @@ private:
             const size_t blk = j.next++, n_blocks = (std::max<size_t>(j.n, 1) + kBlock - 1) / kBlock;
             const uint64_t *s = j.src;
             uint32_t *d = j.dst;
+            const float *rad = j.rad;
+            uint8_t *rad8 = j.rad8;
+            RadiusCodec *codec = j.codec;
             const size_t b = blk * kBlock, e = std::min(j.n, b + kBlock);
             lk.unlock();
-            for (size_t i = b; i < e; i++) d[i] = (uint32_t)s[i] ^ ((uint32_t)(s[i] >> 32) * 0x9E3779B1u);  // fold_id
+            if (s && d)
+                for (size_t i = b; i < e; i++) d[i] = (uint32_t)s[i] ^ ((uint32_t)(s[i] >> 32) * 0x9E3779B1u);  // fold_id
+            if (codec && !codec->failed.load(std::memory_order_relaxed)) {
+                uint32_t last_bits = 0;
+                int last_code = -1;  // (runs of equal radii are common: backbone N, CA, C, O repeat)
+                for (size_t i = b; i < e; i++) {
+                    const uint32_t bt = RadiusCodec::bits(rad[i]);
+                    if (last_code < 0 || bt != last_bits) {
+                        last_code = codec->code(rad[i]);
+                        last_bits = bt;
+                        if (last_code < 0) break;
+                    }
+                    rad8[i] = (uint8_t)last_code;
+                }
+            }
             lk.lock();
             // (the job is still the front one: it leaves the queue only when all its blocks are finished)
             if (++jobs.front().finished == n_blocks) {
@@ -180,10 +233,14 @@ struct rsasa_context {
     // further input / output slots of the pipelined host-buffer path (kSlots sub-batches in flight)
     DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res, in3_x, in3_y, in3_z, in3_r, in3_id, in3_res;
     DeviceBuffer atom_sasa2, out_res2, atom_sasa3, out_res3;
-    DeviceBuffer in_id32[3];                      // host-folded ids of the sub-batch in slot k
-    uint32_t *h_id32 = nullptr;                   // pinned: the folds of a whole host batch on their way to the device
-    size_t h_id32_cap = 0;
-    FoldPool *fold_pool = nullptr;                // created by the first large call with ids in pinned memory
+    // Pipelined host path: everything of a sub-batch that the host prepares - radius table, rebased residue offsets,
+    // folded ids, radius codes - sits in ONE pinned block per sub-batch and crosses the link in ONE copy (every
+    // copy costs the link about 12 us of idle time).
+    DeviceBuffer in_pack[3];                      // that block of the sub-batch in slot k, on the device
+    char *h_pack = nullptr;                       // pinned: the blocks of a whole host batch
+    size_t h_pack_cap = 0;
+    FoldPool *fold_pool = nullptr;                // created by the first large (pipelined) host call
+    RadiusCodec radius_codec;
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
     hipStream_t d2h_stream = nullptr;             // D2H of the previous sub-batch's results meanwhile
     static constexpr int kSlots = 3;
@@ -435,6 +492,8 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     BatchView v{};
     v.x = bt.x; v.y = bt.y; v.z = bt.z; v.radius = bt.radius; v.id = bt.id;
     v.id32 = pd.id32;
+    v.radius8 = pd.radius8;
+    v.radius_table = pd.radius_table;
     v.residue_offsets = bt.residue_offsets;
     v.n_atoms = (uint32_t)N; v.n_structures = (uint32_t)S; v.n_residues = (uint32_t)R;
     v.n_segments = (uint32_t)n_seg;
@@ -684,10 +743,10 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->in3_x, &ctx->in3_y, &ctx->in3_z, &ctx->in3_r, &ctx->in3_id, &ctx->in3_res,
                             &ctx->atom_sasa2, &ctx->out_res2, &ctx->atom_sasa3, &ctx->out_res3,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
-                            &ctx->tr_id, &ctx->tr_res, &ctx->in_id32[0], &ctx->in_id32[1], &ctx->in_id32[2]})
+                            &ctx->tr_id, &ctx->tr_res, &ctx->in_pack[0], &ctx->in_pack[1], &ctx->in_pack[2]})
         release(*b);
     delete ctx->fold_pool;
-    if (ctx->h_id32) (void)hipHostFree(ctx->h_id32);
+    if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     for (auto &kv : ctx->lattices)
         if (kv.second.d) (void)hipFree(kv.second.d);
     for (int i = 0; i < rsasa_context::kSlots; i++) {
@@ -1051,13 +1110,20 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     if (want_res) {
         if (residue_offsets[n_residues] > N)
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets exceed n_atoms");
-        for (size_t k = 0; k < n_residues; k++)
-            if (residue_offsets[k] > residue_offsets[k + 1])
-                return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets must be non-decreasing");
+        uint32_t decreasing = 0;  // (branch-free: vectorised; a million and a half offsets per proteome batch)
+        for (size_t k = 0; k < n_residues; k++) decreasing |= (uint32_t)(residue_offsets[k] > residue_offsets[k + 1]);
+        if (decreasing) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "residue_offsets must be non-decreasing");
     }
 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
+    static const bool h2h_trace = std::getenv("RSASA_H2H_TRACE") != nullptr;  // host-side phases of a pipelined call, to stderr
+    const auto tr_t0 = std::chrono::steady_clock::now();
+    auto tr = [&](const char *what) {
+        if (h2h_trace)
+            std::fprintf(stderr, "h2h %8.1f us  %s\n",
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr_t0).count(), what);
+    };
     if (ctx->n_pending && (rc = wait_pending(ctx))) return rc;
     if (ctx->small_path) {
         rc = run_small_host_batch(ctx, x, y, z, radius, id, structure_offsets, n_structures, probe_radius, n_points,
@@ -1107,6 +1173,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
     const bool piped = cut.size() > 2;
     const size_t n_sub = cut.size() - 1;
+    constexpr size_t kTableWords = 256;  // a sub-batch's offsets block on the device: radius table | residue offsets
     constexpr int kSlots = rsasa_context::kSlots;
     const int n_slots = piped ? kSlots : 1;
     DeviceBuffer *bx[kSlots] = {&ctx->in_x, &ctx->in2_x, &ctx->in3_x}, *by[kSlots] = {&ctx->in_y, &ctx->in2_y, &ctx->in3_y};
@@ -1120,7 +1187,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
         if (id && !piped && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;  // (pipelined: below, unless the ids are folded)
-        if (want_res && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
+        if (want_res && !piped && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
         if ((rc = reserve(ctx, *oa[k], max_atoms * 4))) return rc;
         if (want_res && (rc = reserve(ctx, *orr[k], max_res * 4))) return rc;
     }
@@ -1146,26 +1213,46 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             (void)hipGetLastError();
         }
     }
-    if (fold_ids) {
+    // Radii on the pipelined path: one-byte codes into the table of the batch's distinct radii (RadiusCodec), coded by
+    // the same worker threads.
+    const bool code_radii = piped && !std::getenv("RSASA_NO_RADIUS_CODES");
+    // the sub-batches' pinned blocks: radius table | residue offsets | folded ids | radius codes, 16-byte aligned parts
+    struct Pack { size_t base = 0, o_res = 0, o_id = 0, o_r8 = 0, bytes = 0; };
+    std::vector<Pack> pack(cut.size());
+    if (piped) {
+        auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+        size_t total = 0, largest = 0;
+        for (size_t c = 0; c + 1 < cut.size(); c++) {
+            const size_t na = structure_offsets[cut[c + 1]] - structure_offsets[cut[c]];
+            const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
+            Pack &pk = pack[c];
+            pk.base = total;
+            pk.o_res = kTableWords * 4;
+            pk.o_id = pk.o_res + up16(want_res ? (nr + 1) * 4 : 0);
+            pk.o_r8 = pk.o_id + up16(fold_ids ? na * 4 : 0);
+            pk.bytes = pk.o_r8 + up16(code_radii ? na : 0);
+            total += pk.bytes;
+            largest = std::max(largest, pk.bytes);
+        }
         for (int k = 0; k < n_slots; k++)
-            if ((rc = reserve(ctx, ctx->in_id32[k], max_atoms * 4))) return rc;
-        if (N > ctx->h_id32_cap) {
-            if (ctx->h_id32) {
+            if ((rc = reserve(ctx, ctx->in_pack[k], largest))) return rc;
+        if (total > ctx->h_pack_cap) {
+            if (ctx->h_pack) {
                 RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-                RS_HIP(ctx, hipHostFree(ctx->h_id32));
-                ctx->h_id32 = nullptr;
-                ctx->h_id32_cap = 0;
+                RS_HIP(ctx, hipHostFree(ctx->h_pack));
+                ctx->h_pack = nullptr;
+                ctx->h_pack_cap = 0;
             }
-            const size_t cap = N + N / 4;
-            RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_id32, cap * 4, hipHostMallocDefault));
-            ctx->h_id32_cap = cap;
+            const size_t cap = total + total / 4;
+            RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_pack, cap, hipHostMallocDefault));
+            ctx->h_pack_cap = cap;
         }
-        if (!ctx->fold_pool) {
-            unsigned nt = std::thread::hardware_concurrency() / 4;
-            if (const char *v = std::getenv("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
-            ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)));
-            if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
-        }
+    }
+    if ((fold_ids || code_radii) && !ctx->fold_pool) {
+        unsigned nt = std::thread::hardware_concurrency() / 4;
+        if (const char *v = std::getenv("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
+        ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)));
+        if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
     }
     std::vector<unsigned long long> fold_job(cut.size(), 0);
     // (no fold job may outlive this call: the workers read the caller's id array)
@@ -1204,7 +1291,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
 
     // host copies of the rebased offsets stay alive until their sub-batch has been waited for
     std::vector<uint32_t> so[kSlots];
-    for (int k = 0; k < n_slots && want_res; k++) {
+    for (int k = 0; k < n_slots && want_res && !piped; k++) {
         rsasa_context::HostSlot &hs = ctx->slot[k];
         if (max_res + 1 <= hs.h_res_cap) continue;
         if (hs.h_res) {
@@ -1220,6 +1307,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
     for (int k = 0; k < n_slots && piped && id && !fold_ids; k++)
         if ((rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
+    tr("setup done");
+    std::vector<char> use_codes(cut.size(), 0);  // sub-batch c's radii travel as codes (decided once its coding job is done)
     auto upload = [&](size_t c, hipStream_t st) -> int {
         const int k = (int)(c % kSlots);
         const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
@@ -1229,11 +1318,20 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             RS_HIP(ctx, hipMemcpyAsync(bx[k]->p, x + a0, na * 4, hipMemcpyHostToDevice, st));
             RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
             RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
-            if (fold_ids) RS_HIP(ctx, hipMemcpyAsync(ctx->in_id32[k].p, ctx->h_id32 + a0, na * 4, hipMemcpyHostToDevice, st));
-            else if (id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
+            if (!use_codes[c]) RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
+            if (!fold_ids && id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
         }
-        if (want_res) {
+        if (piped) {
+            // the sub-batch's pinned block (the workers have filled in ids and radius codes): table and offsets, one copy
+            char *blk = ctx->h_pack + pack[c].base;
+            if (use_codes[c]) std::memcpy(blk, ctx->radius_codec.table, kTableWords * 4);
+            if (want_res) {
+                const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
+                uint32_t *ro = reinterpret_cast<uint32_t *>(blk + pack[c].o_res);
+                for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
+            }
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_pack[k].p, blk, pack[c].bytes, hipMemcpyHostToDevice, st));
+        } else if (want_res) {
             const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
             uint32_t *ro = ctx->slot[k].h_res;
             for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
@@ -1322,6 +1420,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must be non-decreasing");
     if (structure_offsets[0] != 0) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must span [0, n_atoms]");
     hipStream_t cp = ctx->copy_stream;
+    if (!ctx->stream2) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     for (int attempt = 0;; attempt++) {
         uint64_t need_cells = 0;
         int err = RSASA_OK;
@@ -1334,12 +1433,17 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
         };
         bool used[kSlots] = {};
-        if (fold_ids) {
-            // all sub-batches' folds, in order, while the uploads follow behind (the previous attempt's copies out of
-            // the pinned block have all been waited for)
+        if (fold_ids || code_radii) {
+            // all sub-batches' folds and radius codes, in order, while the uploads follow behind (the previous
+            // attempt's copies out of the pinned blocks have all been waited for)
+            if (code_radii) ctx->radius_codec.reset();
             for (size_t c = 0; c < n_sub; c++) {
                 const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
-                fold_job[c] = ctx->fold_pool->submit(id + a0, ctx->h_id32 + a0, na);
+                char *blk = ctx->h_pack + pack[c].base;
+                fold_job[c] = ctx->fold_pool->submit(fold_ids ? id + a0 : nullptr,
+                                                     fold_ids ? reinterpret_cast<uint32_t *>(blk + pack[c].o_id) : nullptr, na,
+                                                     radius + a0, code_radii ? reinterpret_cast<uint8_t *>(blk + pack[c].o_r8) : nullptr,
+                                                     code_radii ? &ctx->radius_codec : nullptr);
             }
             fold_drain.pool = ctx->fold_pool;
             fold_drain.last = fold_job[n_sub - 1];
@@ -1352,10 +1456,16 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 check(k);
                 if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
             }
-            if (fold_ids) ctx->fold_pool->wait(fold_job[c]);
+            if (fold_ids || code_radii) ctx->fold_pool->wait(fold_job[c]);
+            use_codes[c] = code_radii && !ctx->radius_codec.failed.load();
+            if (c == 0) tr("first sub-batch coded");
             if ((rc = upload(c, cp))) return rc;
             RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
-
+            // consecutive sub-batches alternate between the context's two workspaces and launch streams: a
+            // sub-batch's grid build then runs beside its predecessor's occlusion kernel (enqueue_batch chains the
+            // occlusion kernels themselves)
+            const int w = (int)(c & 1);
+            hipStream_t st = w ? ctx->stream2 : ctx->stream;
             RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
             if (used[k]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k], 0));  // output slot k has left the device
             const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
@@ -1366,11 +1476,14 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             pd.batch.z = (const float *)bz[k]->p;
             pd.batch.radius = (const float *)br[k]->p;
             pd.batch.id = fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
-            pd.id32 = fold_ids ? (const uint32_t *)ctx->in_id32[k].p : nullptr;
+            const char *dblk = (const char *)ctx->in_pack[k].p;
+            pd.id32 = fold_ids ? (const uint32_t *)(dblk + pack[c].o_id) : nullptr;
             pd.batch.structure_offsets_host = so[k].data();
             pd.batch.n_structures = s1 - s0;
             pd.batch.n_atoms = na;
-            pd.batch.residue_offsets = nr ? (const uint32_t *)bo[k]->p : nullptr;
+            pd.batch.residue_offsets = nr ? (const uint32_t *)(dblk + pack[c].o_res) : nullptr;
+            pd.radius8 = use_codes[c] ? (const uint8_t *)(dblk + pack[c].o_r8) : nullptr;
+            pd.radius_table = use_codes[c] ? (const float *)dblk : nullptr;
             pd.batch.n_residues = nr;
             pd.batch.out_atom_sasa = (float *)oa[k]->p;
             pd.batch.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
@@ -1378,11 +1491,13 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             pd.probe = probe_radius;
             pd.n_points = n_points;
             pd.stream = st;
+            pd.ws = w;
             if ((rc = enqueue_batch(ctx, pd, ctx->slot[k]))) return rc;
             RS_HIP(ctx, hipEventRecord(ctx->ev_done[k], st));
             RS_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_done[k], 0));
             if ((rc = copy_out(c))) return rc;
             used[k] = true;
+            if (h2h_trace) tr(c + 1 == n_sub ? "last sub-batch enqueued" : "sub-batch enqueued");
         }
         for (int k = 0; k < kSlots; k++) {
             if (!used[k]) continue;
@@ -1391,6 +1506,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             if ((rc = drain(k))) return rc;
         }
         RS_HIP(ctx, hipStreamSynchronize(dn));
+        tr("all done");
         if (err) return err;
         if (!need_cells) return RSASA_OK;
         if (need_cells >= 0xFFFFFFF0ull || attempt >= 3)

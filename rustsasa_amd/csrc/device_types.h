@@ -81,6 +81,8 @@ struct BatchView {
                            // the binning kernels read these instead of `id`, no sorted copy of the 64-bit ids is kept, and
                            // `id` (device-accessible, possibly mapped host memory) is only read by the general occlusion
                            // kernel for the few atoms whose folds collide
+    const uint8_t *radius8;  // nullable (pipelined host path): the radii as one-byte codes into `radius_table`, read instead of
+    const float *radius_table;  // `radius` (a batch has few distinct radii: 1 byte per atom crosses the link, not 4)
     const uint32_t *residue_offsets;
     uint32_t n_atoms, n_structures, n_residues, n_segments;
     float probe;

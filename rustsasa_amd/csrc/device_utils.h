@@ -111,6 +111,13 @@ __device__ __forceinline__ uint64_t load_id(const uint64_t *id, const uint32_t *
     return id32 ? (uint64_t)id32[i] : id[i];
 }
 
+// The radius of input atom i: its f32, or the table entry its one-byte code names (the same bits: the host built
+// the table from the batch's own values).
+__device__ __forceinline__ float load_radius(const float *radius, const uint8_t *radius8, const float *table, uint32_t i)
+{
+    return radius8 ? table[radius8[i]] : radius[i];
+}
+
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 }  // namespace

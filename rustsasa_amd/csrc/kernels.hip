@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     float mr = 0.0f;
     bool odd_r = false;  // a radius outside [0, 64] (or NaN): see StructGrid::odd_radii
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
-        float x = b.x[i], y = b.y[i], z = b.z[i], r = b.radius[i];
+        float x = b.x[i], y = b.y[i], z = b.z[i], r = load_radius(b.radius, b.radius8, b.radius_table, i);
         odd_r |= !(r >= 0.0f && r <= 64.0f);
         mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
         mny = fminf(mny, y); mxy = fmaxf(mxy, y);
@@ -307,7 +307,8 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
     }
     const uint32_t tid = threadIdx.x;
     const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
-    const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z, *__restrict__ pr = b.radius;
+    const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z;
+    auto pr = [&](uint32_t i) { return load_radius(b.radius, b.radius8, b.radius_table, i); };
     const uint32_t *__restrict__ pid32 = b.id32;
     const uint64_t *__restrict__ pid = pid32 ? reinterpret_cast<const uint64_t *>(pid32) : b.id;  // (non-null: the batch has ids)
     uint32_t *__restrict__ rank_of = b.rank_of;  // sorted position of the atoms without a slot
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                 const uint32_t i = min(a0 + tid + 1024u * (k0 + k), a1 - 1u);
                 x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
                 if (SINGLE) {
-                    kr[k0 + k] = pr[i];
+                    kr[k0 + k] = pr(i);
                     if (pid) kid[k0 + k] = load_id(b.id, pid32, i);
                 }
             }
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                     id[k] = kid[k0 + k];
                 } else if (rcell[k0 + k] < n_cells) {
                     const uint32_t i = a0 + tid + 1024u * (k0 + k);
-                    v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
+                    v[k] = make_float4(px[i], py[i], pz[i], pr(i));
                     if (pid) id[k] = load_id(b.id, pid32, i);
                 }
             }
@@ -488,7 +489,7 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
         for (int k = 0; k < 4; k++) {
             const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
             pos[k] = rank_of[i];  // (another window's atom: not ours to read, ignored below)
-            v[k] = make_float4(px[i], py[i], pz[i], pr[i]);
+            v[k] = make_float4(px[i], py[i], pz[i], pr(i));
             id[k] = pid ? load_id(b.id, pid32, i) : 0ull;
         }
 #pragma unroll
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
     const uint32_t part = kSegmentAtoms / kSegmentParts, p0 = seg.begin + (blockIdx.x % kSegmentParts) * part;
     for (uint32_t i = p0 + threadIdx.x; i < min(seg.end, p0 + part); i += blockDim.x) {
         const uint32_t pos = b.cells[b.cell_of[i]] + b.rank_of[i];
-        b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], b.radius[i]);
+        b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], load_radius(b.radius, b.radius8, b.radius_table, i));
         b.sorted_orig[pos] = i;
         b.sid_sorted[pos] = s;
         if (b.sorted_id32) { const uint64_t v = load_id(b.id, b.id32, i); if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }

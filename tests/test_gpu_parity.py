@@ -884,6 +884,20 @@ def test_host_batch_pipelined_sub_batches(ctx):
         lo, hi = int(b.structure_offsets[s]), int(b.structure_offsets[s + 1])
         want = po.calculate_sasa_internal(b.x[lo:hi], b.y[lo:hi], b.z[lo:hi], b.radius[lo:hi], ids2[lo:hi], PROBE, 100, 8)
         assert np.array_equal(a5[lo:hi], want)
+    # Radii cross the link as one-byte codes into the table of the batch's distinct radii (coded by the same
+    # worker threads).  More than 256 distinct radii: the f32 radii are uploaded instead - from the start, or from
+    # the sub-batch in which the 257th turns up.
+    r_many = b.radius.copy()
+    r_many += (rng.integers(0, 4000, b.n_atoms) * np.float32(1e-4)).astype(np.float32)   # thousands of distinct values
+    r_late = b.radius.copy()
+    late = b.n_atoms * 2 // 3
+    r_late[late:] += (rng.integers(0, 400, b.n_atoms - late) * np.float32(1e-3)).astype(np.float32)
+    for rr in (r_many, r_late):
+        got, _ = ctx.calculate_sasa_batch(pin(b.x), pin(b.y), pin(b.z), pin(rr), pin(b.ids), b.structure_offsets, PROBE, 100)
+        for s in rng.choice(b.n_structures, 5, replace=False).tolist() + [b.n_structures - 1]:
+            lo, hi = int(b.structure_offsets[s]), int(b.structure_offsets[s + 1])
+            want = po.calculate_sasa_internal(b.x[lo:hi], b.y[lo:hi], b.z[lo:hi], rr[lo:hi], b.ids[lo:hi], PROBE, 100, 8)
+            assert np.array_equal(got[lo:hi], want)
 
 
 def test_small_host_batches_take_the_short_path_and_agree(monkeypatch):

@@ -30,7 +30,7 @@ kernel = re.search(r"dispatch \d+: (.*?) grid=", txt).group(1).strip()
 
 
 sys.path.insert(0, ROOT)
-import bench  # noqa: E402  (kernel_source_hash: the build these counters belong to)
+import bench as bench_py  # noqa: E402  (kernel_source_hash: the build these counters belong to)
 
 fetch_kb, write_kb = val("FETCH_SIZE"), val("WRITE_SIZE")
 hit, miss = val("TCC_HIT_sum"), val("TCC_MISS_sum")
@@ -49,7 +49,7 @@ out = {
     "tcc_hit_rate": round(hit / (hit + miss), 4),
     "valu_insts_per_launch": val("SQ_INSTS_VALU"),
     "salu_insts_per_launch": val("SQ_INSTS_SALU"),
-    "kernel_source_sha16": bench.kernel_source_hash(),
+    "kernel_source_sha16": bench_py.kernel_source_hash(),
 }
 try:
     # vector + matrix ALU occupancy: plain vector instructions at the 2.7 cycles each costs a SIMD at full occupancy
@@ -82,6 +82,6 @@ if os.path.exists(pu):
             "source": "rocprofv3 --pmc SQ_INSTS_* (tools/profile_round.sh, profiles/" + prefix + "_pmc_uniform1m.txt)",
             "valu_insts_per_launch": vu("SQ_INSTS_VALU"), "mfma_insts_per_launch": vu("SQ_INSTS_MFMA"),
             "salu_insts_per_launch": vu("SQ_INSTS_SALU"), "lds_insts_per_launch": vu("SQ_INSTS_LDS"),
-            "kernel_source_sha16": bench.kernel_source_hash()}
+            "kernel_source_sha16": bench_py.kernel_source_hash()}
     json.dump(outu, open(os.path.join(dst, "pmc_uniform1m.json"), "w"), indent=2)
     print(json.dumps(outu, indent=1))
