@@ -33,6 +33,9 @@ def structure(rng):
         xyz = rng.uniform(0, 1, (n, 3)) * np.array([120.0, 120.0, 0.5])
     xyz += rng.uniform(-500, 500, 3)
     r = rng.uniform(1.0, 2.2, n) if rng.random() < 0.8 else np.full(n, rng.uniform(1.2, 2.0))
+    if rng.random() < 0.08 and n > 3:  # radii the matrix-core kernel hands to the general one: negative, zero, huge, tiny
+        k = rng.integers(n, size=max(1, n // 200))
+        r[k] = rng.choice([-1.0, 0.0, 70.0, 63.9, 64.1, 0.05], size=len(k))
     return xyz.astype(np.float32), r.astype(np.float32)
 
 
@@ -49,8 +52,10 @@ with rustsasa_amd.Context(0) as ctx:
         if rng.random() < 0.3 and len(ids) > 4:  # some duplicated ids
             k = rng.integers(len(ids), size=max(1, len(ids) // 50)); ids[k] = ids[(k + 1) % len(ids)]
         use_ids = ids if rng.random() < 0.8 else None
-        n_points = int(rng.choice([1, 20, 64, 100, 100, 100, 128, 200, 960, 1000]))
-        probe = float(rng.choice([1.4, 1.4, 0.0, 0.7, 2.5]))
+        n_points = int(rng.choice([1, 20, 64, 100, 100, 100, 103, 110, 128, 131, 200, 960, 1000, 1003]))
+        probe = float(rng.choice([1.4, 1.4, 1.4, 0.0, 0.7, 2.5]))
+        if len(xyz) < 3000 and rng.random() < 0.1:
+            probe = 33.0  # (a probe the matrix-core kernel does not take; the oracle needs minutes for it on large inputs)
         x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
         # random residues: consecutive runs of atoms that never cross a structure boundary
         cuts = set(so.tolist())
