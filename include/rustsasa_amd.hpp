@@ -37,6 +37,8 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <memory>
+#include <memory_resource>
 #include <utility>
 #include <vector>
 
@@ -58,24 +60,39 @@ struct AtomRecord {
 struct Conformer {
     std::string name;     // residue name of this conformer
     std::string alt_loc;  // "" when none
-    std::vector<AtomRecord> atoms;
+    std::pmr::vector<AtomRecord> atoms;
 };
 
 struct Residue {
     std::int64_t serial_number = 0;
     std::string insertion_code;  // "" when none
-    std::vector<Conformer> conformers;
+    std::pmr::vector<Conformer> conformers;
     // Some(name) iff every conformer has the same name (pdbtbx Residue::name()).
     bool name(std::string *out) const;
 };
 
 struct Chain {
     std::string id;
-    std::vector<Residue> residues;
+    std::pmr::vector<Residue> residues;
 };
 
+// The model's nodes (the vectors of chains, residues, conformers and atoms) use std::pmr allocators: a structure the
+// readers build keeps them in ONE pool that is released in a few blocks (a directory of structures is millions of
+// nodes, and giving them back to malloc one by one took longer than parsing them); a default-constructed Structure,
+// and every copy, uses the default resource (new / delete).
 struct Structure {
-    std::vector<Chain> chains;
+    Structure() = default;
+    explicit Structure(std::size_t pool_bytes);  // nodes from a pool of about this size (it grows when it has to)
+    Structure(const Structure &other);           // deep copy, on the default resource
+    Structure(Structure &&other) noexcept;
+    Structure &operator=(const Structure &other);
+    Structure &operator=(Structure &&other) noexcept;
+
+  private:
+    std::unique_ptr<std::pmr::monotonic_buffer_resource> pool_;  // (declared first: released after `chains`)
+
+  public:
+    std::pmr::vector<Chain> chains;
     std::vector<std::string> warnings;
     // Reads a PDB (ATOM/HETATM fixed columns) or mmCIF (_atom_site loop) file,
     // chosen by extension (.cif / .mmcif => mmCIF).  Throws std::runtime_error.

@@ -298,18 +298,19 @@ inline bool same(const std::string &s, const TextView &v)
 // per-line strings, and consecutive atoms of one conformer - nearly all of them - skip the searches.
 struct ModelBuilder {
     Structure &s;
+    std::pmr::memory_resource *const mem = s.chains.get_allocator().resource();  // the structure's pool
     size_t ci = (size_t)-1, ri = (size_t)-1, fi = (size_t)-1;  // chain / residue / conformer of the previous atom
 
     // a new, default-constructed record at the end of the atom's conformer
     AtomRecord &add(const TextView &chain_id, std::int64_t res_seq, const TextView &icode, const TextView &res_name,
-                    const TextView &alt)
+                    const TextView &alt, size_t expect = 16)
     {
         if (ci == (size_t)-1 || !same(s.chains[ci].id, chain_id)) {
             ci = (size_t)-1;
             for (size_t k = s.chains.size(); k-- > 0;)
                 if (same(s.chains[k].id, chain_id)) { ci = k; break; }
             if (ci == (size_t)-1) {
-                s.chains.push_back(Chain{std::string(chain_id.first, chain_id.second), {}});
+                s.chains.push_back(Chain{std::string(chain_id.first, chain_id.second), std::pmr::vector<Residue>(mem)});
                 ci = s.chains.size() - 1;
             }
             ri = fi = (size_t)-1;
@@ -320,7 +321,7 @@ struct ModelBuilder {
             for (size_t k = chain.residues.size(); k-- > 0;)
                 if (chain.residues[k].serial_number == res_seq && same(chain.residues[k].insertion_code, icode)) { ri = k; break; }
             if (ri == (size_t)-1) {
-                chain.residues.push_back(Residue{res_seq, std::string(icode.first, icode.second), {}});
+                chain.residues.push_back(Residue{res_seq, std::string(icode.first, icode.second), std::pmr::vector<Conformer>(mem)});
                 ri = chain.residues.size() - 1;
             }
             fi = (size_t)-1;
@@ -331,12 +332,13 @@ struct ModelBuilder {
             for (size_t k = 0; k < res.conformers.size(); k++)
                 if (same(res.conformers[k].name, res_name) && same(res.conformers[k].alt_loc, alt)) { fi = k; break; }
             if (fi == (size_t)-1) {
-                res.conformers.push_back(Conformer{std::string(res_name.first, res_name.second), std::string(alt.first, alt.second), {}});
+                res.conformers.push_back(Conformer{std::string(res_name.first, res_name.second), std::string(alt.first, alt.second),
+                                                   std::pmr::vector<AtomRecord>(mem)});
                 fi = res.conformers.size() - 1;
             }
         }
-        std::vector<AtomRecord> &atoms = res.conformers[fi].atoms;
-        if (atoms.capacity() == atoms.size()) atoms.reserve(std::max<size_t>(16, 2 * atoms.size()));
+        std::pmr::vector<AtomRecord> &atoms = res.conformers[fi].atoms;
+        if (atoms.capacity() == atoms.size()) atoms.reserve(std::max<size_t>(expect, 2 * atoms.size()));
         atoms.emplace_back();
         return atoms.back();
     }
@@ -383,12 +385,46 @@ inline LineView next_line(const char *&cur, const char *end)
 
 }  // namespace
 
+// ---- Structure: special members (see the header) ----
+Structure::Structure(std::size_t pool_bytes)
+    : pool_(new std::pmr::monotonic_buffer_resource(std::max<std::size_t>(pool_bytes, 4096))), chains(pool_.get())
+{
+}
+Structure::Structure(const Structure &other) : chains(other.chains.begin(), other.chains.end()), warnings(other.warnings) {}
+Structure::Structure(Structure &&other) noexcept
+    : pool_(std::move(other.pool_)), chains(std::move(other.chains)), warnings(std::move(other.warnings))
+{
+    // the moved-from object must not keep an allocator that points into a pool it no longer owns
+    other.chains.~vector();
+    new (&other.chains) std::pmr::vector<Chain>();
+}
+Structure &Structure::operator=(const Structure &other)
+{
+    if (this != &other) {
+        Structure copy(other);
+        *this = std::move(copy);
+    }
+    return *this;
+}
+Structure &Structure::operator=(Structure &&other) noexcept
+{
+    if (this != &other) {  // (pmr containers do not take the allocator along on assignment: rebuild in place)
+        this->~Structure();
+        new (this) Structure(std::move(other));
+    }
+    return *this;
+}
+
+// A pool for the model of `text_bytes` of PDB / mmCIF text: an atom record takes 1.5 bytes per byte of an 80-column
+// line, residues and conformers a little more.
+static inline std::size_t pool_bytes_for(std::size_t text_bytes) { return text_bytes * 2 + 4096; }
+
 Structure Structure::from_pdb_text(const std::string &text)
 {
-    Structure s;
+    Structure s(pool_bytes_for(text.size()));
     ModelBuilder model{s};
     bool in_first_model = true, seen_model = false;
-    std::size_t counter = 0;
+    std::size_t counter = 0, run_left = 0, run_len = 1;
     const char *cur = text.data(), *const end = text.data() + text.size();
     while (cur < end) {
         const LineView line = next_line(cur, end);
@@ -402,9 +438,25 @@ Structure Structure::from_pdb_text(const std::string &text)
         if (!(is_atom || is_het) || !in_first_model) continue;
         if (line.n < 54) { s.warnings.push_back("short ATOM record skipped"); continue; }
         counter++;
+        // records of one conformer usually follow each other: count them (columns 17-27: alternate location, residue
+        // name, chain, number, insertion code) so that the conformer's atoms are allocated once, at their final size
+        if (run_left == 0) {
+            run_left = 1;
+            if (line.n >= 27) {
+                const char *scan = cur;
+                while (scan < end) {
+                    const LineView nl = next_line(scan, end);
+                    if (nl.starts_with("ANISOU")) continue;  // (between an atom and the next one)
+                    if (nl.n < 54 || !(nl.starts_with("ATOM  ") || nl.starts_with("HETATM")) || std::memcmp(nl.p + 16, line.p + 16, 11) != 0) break;
+                    run_left++;
+                }
+            }
+            run_len = run_left;
+        }
+        run_left--;
         const TextView name = field_view(line, 13, 16);
         AtomRecord &rec = model.add(field_view(line, 22, 22), column_int(line, 23, 26, nullptr), field_view(line, 27, 27),
-                                    field_view(line, 18, 20), field_view(line, 17, 17));
+                                    field_view(line, 18, 20), field_view(line, 17, 17), run_len);
         rec.hetero = is_het;
         bool serial_ok = false;
         const long sv = column_int(line, 7, 11, &serial_ok);
@@ -470,7 +522,7 @@ inline long token_long(const TextView &t)
 
 Structure Structure::from_mmcif_text(const std::string &text)
 {
-    Structure s;
+    Structure s(pool_bytes_for(text.size()));
     ModelBuilder model{s};
     std::vector<std::string> cols;
     std::vector<TextView> tok;
@@ -1164,6 +1216,33 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     FilesTimings t{};
     std::mutex mu_t;
 
+    // Destroying a chunk's structures competes with the parse pool: free() takes the lock of the arena a block came
+    // from - the arenas the parse threads are allocating from.  Measured on the 4 363-file set (32 parse threads, one
+    // block per vector of the model): freed by 16 threads on the GPU workers' path the parse pool needed 0.17-0.25 s of
+    // wall time per call, by 4 threads 0.10 s, by one 0.07 s (but then the freeing itself took 0.25 s).  Hence the
+    // per-structure pools (include/rustsasa_amd.hpp) and ONE reaper with a few threads, off everybody's path.
+    std::mutex mu_dead;
+    std::condition_variable cv_dead, cv_dead_room;
+    std::deque<std::unique_ptr<Chunk>> dead;
+    bool no_more_dead = false;
+    const unsigned free_threads = 4;
+    std::thread reaper([&] {
+        for (;;) {
+            std::unique_ptr<Chunk> c;
+            {
+                std::unique_lock<std::mutex> lk(mu_dead);
+                cv_dead.wait(lk, [&] { return no_more_dead || !dead.empty(); });
+                if (dead.empty()) return;
+                c = std::move(dead.front());
+                dead.pop_front();
+            }
+            cv_dead_room.notify_one();
+            parallel_for(c->n, free_threads, [&](size_t i) {
+                Structure s = std::move(c->pdbs[i]);
+                Prepared pr = std::move(c->prep[i]);
+            });
+        }
+    });
     auto worker = [&](rsasa_context_t *ctx) {
         OptionValues mine = o;
         mine.context = ctx;
@@ -1186,12 +1265,13 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
             std::vector<Result<typename Level::Output>> out;
             run_batch<Level>(mine, ptrs, c->prep, out, std::max(1u, host_threads / 2));
             for (size_t i = 0; i < c->n; i++) all[c->base + i] = std::move(out[i]);
-            // the parsed structures are freed here, off the producer's path (many small blocks)
-            parallel_for(c->n, std::max(1u, host_threads / 2), [&](size_t i) {
-                Structure s = std::move(c->pdbs[i]);
-                Prepared pr = std::move(c->prep[i]);
-            });
-            c.reset();
+            // the parsed structures (millions of small blocks) go to the reaper thread
+            {
+                std::unique_lock<std::mutex> lk(mu_dead);
+                cv_dead_room.wait(lk, [&] { return dead.size() < 4; });  // (memory stays bounded if freeing falls behind)
+                dead.push_back(std::move(c));
+            }
+            cv_dead.notify_one();
             const double dt = std::chrono::duration<double>(Clock::now() - t1).count();
             std::lock_guard<std::mutex> lk(mu_t);
             t.compute_seconds += dt;
@@ -1244,6 +1324,12 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     }
     cv_pop.notify_all();
     for (auto &th : workers) th.join();
+    {
+        std::lock_guard<std::mutex> lk(mu_dead);
+        no_more_dead = true;
+    }
+    cv_dead.notify_all();
+    reaper.join();
     t.total_seconds = std::chrono::duration<double>(Clock::now() - t_begin).count();
     t.n_files = paths.size();
     if (timings) *timings = t;

@@ -65,11 +65,13 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     size_t batch = 0;
     bool full = false;
     int workers = 0, devices = 1;  // --workers K: K GPU worker contexts, on devices k % --devices
+    int calls = 1;                 // --calls N: process_files N times in this process (the last call's results are printed)
     for (int i = 4; i < argc; i++) {
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (size_t)std::atol(argv[i + 1]);
         if (!std::strcmp(argv[i], "--workers") && i + 1 < argc) workers = std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, std::atoi(argv[i + 1]));
+        if (!std::strcmp(argv[i], "--calls") && i + 1 < argc) calls = std::max(1, std::atoi(argv[i + 1]));
         if (!std::strcmp(argv[i], "--full")) full = true;
     }
     std::vector<rsasa_context_t *> ctxs;
@@ -86,11 +88,16 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     auto opts = make<L>(argc - 1, argv + 1);
     if (!ctxs.empty()) opts.with_contexts(ctxs);
     auto res = opts.process_files(paths, threads, batch, &t);
+    std::string call_s = std::to_string(t.total_seconds);  // every call's wall time: the first one includes the HIP runtime's start-up
+    for (int k = 1; k < calls; k++) {
+        res = opts.process_files(paths, threads, batch, &t);
+        call_s += "," + std::to_string(t.total_seconds);
+    }
     for (rsasa_context_t *c : ctxs) rsasa_context_destroy(c);
     size_t n_ok = 0;
     for (const auto &r : res) n_ok += r.ok();
-    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"results\":[",
-                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds);
+    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"calls_s\":[%s],\"results\":[",
+                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds, call_s.c_str());
     for (size_t i = 0; i < res.size(); i++) {
         std::printf("%s", i ? "," : "");
         if (!res[i].ok()) {

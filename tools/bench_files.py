@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--workers", type=int, default=0, help="GPU worker contexts (0 = the default context)")
     ap.add_argument("--devices", type=int, default=1)
+    ap.add_argument("--calls", type=int, default=3, help="process_files calls per process (the first includes HIP start-up)")
     args = ap.parse_args()
     d = args.dir or tempfile.mkdtemp(prefix="rsasa_files_")
     rng = np.random.default_rng(bw.PROTEOME_SEED)
@@ -101,16 +102,21 @@ def main():
     best = None
     for _ in range(args.repeat):
         cmd = [CLI, "files", "residue", lst, "--threads", str(args.threads), "--batch", str(args.batch),
-               "--workers", str(args.workers), "--devices", str(args.devices)]
+               "--workers", str(args.workers), "--devices", str(args.devices), "--calls", str(args.calls)]
         p = subprocess.run(cmd, capture_output=True, text=True)
         assert p.returncode == 0, p.stderr[-500:]
         if os.environ.get("RSASA_FILES_TRACE"):
             sys.stderr.write(p.stderr[-3000:])
         r = json.loads(p.stdout)
         r.pop("results")
+        r["first_call_s"] = r["calls_s"][0]
+        r["later_calls_s"] = min(r["calls_s"][1:]) if len(r["calls_s"]) > 1 else None
+        r["total_s"] = r["first_call_s"]
         if best is None or r["total_s"] < best["total_s"]:
             best = r
     best.update({"files_per_s": round(best["n_files"] / best["total_s"], 1),
+                 "files_per_s_later_calls": round(best["n_files"] / best["later_calls_s"], 1) if best["later_calls_s"] else None,
+                 "note": "files_per_s: a fresh process's first call (HIP runtime start-up inside); later calls of the same process: files_per_s_later_calls",
                  "atoms_per_file": round(atoms / args.files, 1), "generation_s": round(gen_s, 1),
                  "host_threads": args.threads or os.cpu_count(),
                  "bytes_on_disk": sum(os.path.getsize(p) for p in paths)})
