@@ -122,6 +122,46 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc >= 3 && std::string(argv[1]) == "model-selftest") {
+        // the structure model's copy / move rules (its nodes live in a pool the Structure owns): every copy and every
+        // moved-to object must stay whole after its source is gone
+        const std::string want = Structure::open(argv[2]).to_pdb_text();
+        const size_t n = Structure::open(argv[2]).atom_count();
+        int bad = 0;
+        auto check = [&](const Structure &s, const char *what) {
+            if (s.atom_count() != n || s.to_pdb_text() != want) { std::fprintf(stderr, "model-selftest: %s differs\n", what); bad++; }
+        };
+        {
+            auto src = std::make_unique<Structure>(Structure::open(argv[2]));
+            Structure copy(*src);
+            Structure copy_assigned;
+            copy_assigned = *src;
+            Structure moved(std::move(*src));
+            if (!src->chains.empty()) { std::fprintf(stderr, "model-selftest: moved-from structure is not empty\n"); bad++; }
+            src->chains.push_back(Chain{"Z", {}});  // a moved-from structure is usable (and uses its own memory)
+            src.reset();
+            check(copy, "copy");
+            check(copy_assigned, "copy-assigned");
+            check(moved, "moved");
+            Structure move_assigned = Structure::open(argv[2]);  // (a pooled target)
+            move_assigned = std::move(moved);
+            check(move_assigned, "move-assigned");
+            move_assigned = *&move_assigned;  // self-assignment
+            check(move_assigned, "self-assigned");
+            std::vector<Structure> many;
+            for (int i = 0; i < 9; i++) many.push_back(i % 2 ? Structure(copy) : Structure::open(argv[2]));  // (reallocations move)
+            many.erase(many.begin() + 1, many.begin() + 4);
+            for (const Structure &s : many) check(s, "vector element");
+            Chain one = many.front().chains.front();  // a copied chain is independent of the structure
+            many.clear();
+            size_t atoms = 0;
+            for (const Residue &r : one.residues)
+                for (const Conformer &c : r.conformers) atoms += c.atoms.size();
+            if (atoms == 0) { std::fprintf(stderr, "model-selftest: copied chain is empty\n"); bad++; }
+        }
+        std::printf("{\"ok\":%s,\"atoms\":%zu}\n", bad ? "false" : "true", n);
+        return bad ? 1 : 0;
+    }
     if (argc >= 4 && std::string(argv[1]) == "parse-bench") {
         // reader micro-benchmark: open + parse the file `reps` times on one thread
         const int reps = std::atoi(argv[3]);

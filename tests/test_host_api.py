@@ -319,6 +319,15 @@ def test_bfactor_write_back(tmp_path):
     assert p.returncode == 3 and "cannot be mapped back" in p.stderr
 
 
+@pytest.mark.parametrize("name", ["1jcd.pdb", "example.cif", "freesasa/4c1a.pdb"])
+def test_structure_copies_and_moves_keep_their_nodes(name):
+    """The model's nodes live in a pool the Structure owns: copies, moved-to objects and vector elements must stay
+    whole after their source is gone (sasa_host_cli model-selftest; tools/fuzz_reader.py --asan runs it sanitized)."""
+    p = subprocess.run([CLI, "model-selftest", sio.data_path(name)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert json.loads(p.stdout)["ok"] is True
+
+
 @pytest.mark.gpu
 def test_json_shape_matches_serde():
     p = subprocess.run([CLI, "residue", sio.data_path("2drt.pdb")], capture_output=True, text=True)

@@ -93,6 +93,8 @@ def main():
                                "-I", os.path.join(ROOT, "include"), os.path.join(src, "host_api.cpp"),
                                os.path.join(src, "sasa_host_cli.cpp"), "-o", cli, "-L", lib, "-lrustsasa_amd",
                                "-Wl,-rpath," + lib, "-lpthread"])
+        for name in ("1jcd.pdb", "example.cif"):  # the model's copy / move rules under the sanitizers
+            subprocess.check_call([cli, "model-selftest", os.path.join(DATA, name)], stdout=subprocess.DEVNULL)
     bad = run_cases(cli, args.n)
     for f in bad:
         print("FAIL", *f)
