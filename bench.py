@@ -480,8 +480,9 @@ def main():
                           "occlusion": round(occl, 4),
                           "residue_sums": round(float(np.mean(agg_ms)), 4),
                           "note": "HIP events on each batch's launch stream over the timed region; a batch's grid build "
-                                  "runs beside the previous batch's occlusion kernel (so its wall time is stretched: alone "
-                                  "it takes one_at_a_time.grid_build_kernel_ms), occlusion kernels run one after the other"},
+                                  "is enqueued beside the previous batch's occlusion kernel and mostly waits for it (its "
+                                  "wall time here includes that wait: alone it takes one_at_a_time.grid_build_kernel_ms), "
+                                  "occlusion kernels run one after the other"},
         }
         if h2h:
             line["host_to_host"] = h2h

@@ -525,8 +525,8 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     // batch-wide binning, which is bandwidth bound and runs next to the compute-bound occlusion kernel.
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[0], st));
     launch_grid_prepare(v, st);
-    // Two batches in flight: this one's grid build (bandwidth bound, many small kernels) runs beside the other one's
-    // occlusion kernel, its occlusion kernel behind it.
+    // Two batches in flight: this one's grid build is enqueued beside the other one's occlusion kernel (it gets the CUs
+    // when that kernel's workgroups retire: the kernel leaves a CU no room), its occlusion kernel behind it.
     rsasa_context::Workspace &other = ctx->ws[pd.ws ^ 1];
     const bool chain = other.occ_recorded && !std::getenv("RSASA_FREE_OVERLAP");
     const bool overlap = ctx->overlap_tail && has_tail;
@@ -1462,8 +1462,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             if ((rc = upload(c, cp))) return rc;
             RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
             // consecutive sub-batches alternate between the context's two workspaces and launch streams: a
-            // sub-batch's grid build then runs beside its predecessor's occlusion kernel (enqueue_batch chains the
-            // occlusion kernels themselves)
+            // sub-batch's grid build is then queued beside its predecessor's occlusion kernel and starts in its tail
+            // (enqueue_batch chains the occlusion kernels themselves)
             const int w = (int)(c & 1);
             hipStream_t st = w ? ctx->stream2 : ctx->stream;
             RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
