@@ -6,7 +6,8 @@
 #   bench_under_rocprof.json   the bench line of that profiled run
 #   pmc.txt                    PMC summaries of the occlusion kernel (separate passes, no tracing): instruction mix, waits,
 #                              matrix-pipe busy / co-execution cycles, GRBM_GUI_ACTIVE (clock), FETCH_SIZE, WRITE_SIZE, TCC hits
-#   bench_uniform1m.json, single_and_pcie.json, files_mode.json
+#   bench_uniform1m.json, single_and_pcie.json, files_mode.json, files_mode_1500.json, bench_shard_of_8.json,
+#   two_in_flight.txt, bench_run2.json (a second default run at the end)
 tag=${1:-round}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -29,6 +30,10 @@ python3 tools/pmc_summary.py "$out/pmcu_*/**/*counter_collection.csv" > $out/pmc
 rm -rf $out/pmcu_a
 python3 bench.py --workload uniform1m --cpu-seconds 0 --h2h-steps 0 --two-steps 0 > $out/u1m.log 2>&1; tail -1 $out/u1m.log > $out/bench_uniform1m.json
 python3 tools/bench_single.py 2>/dev/null > $out/single_and_pcie.json
-python3 tools/bench_files.py --files 4363 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json
+python3 tools/bench_files.py --files 4363 --repeat 3 --calls 4 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json
+python3 tools/bench_files.py --files 1500 --repeat 3 --calls 4 > $out/files1500.log 2>&1; tail -1 $out/files1500.log > $out/files_mode_1500.json
+python3 bench.py --shard-of 8 > $out/shard8.log 2>&1; tail -1 $out/shard8.log > $out/bench_shard_of_8.json
+python3 tools/bench_two_in_flight.py 1 8 2>&1 | grep "^shard" > $out/two_in_flight.txt
+python3 bench.py > $out/bench2.log 2>&1; tail -1 $out/bench2.log > $out/bench_run2.json
 rm -rf $out/trace $out/pmc_a $out/pmc_b $out/pmc_c $out/pmc_g $out/pmc_fetch $out/pmc_write $out/pmc_tcc
 ls -la $out; cat $out/bench.json; cat $out/bench_under_rocprof.json; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc.txt
