@@ -84,61 +84,100 @@ def self_launch(args):
     return subprocess.call(cmd)
 
 
+def physical_cores():
+    """Distinct (socket, core) pairs of /proc/cpuinfo (None when it does not say)."""
+    seen, phys = set(), None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                seen.add((phys, line.split(":")[1].strip()))
+    except OSError:
+        pass
+    return len(seen) or None
+
+
 def cpu_baseline(batch, n_points, target_seconds):
     """The oracle (a port of the reference's CPU path) on a bounded sample of the same workload, SURVEY 8d:
-    (i) one thread, (ii) all host cores with structure-level parallelism (mirrors src/main.rs:375,439);
-    same inputs, wall clock, best of three after a warm-up.  Returns the bench-line object, the oracle's
-    per-atom values of the all-cores sample and its structure count."""
+    (i) one thread, (ii) all host threads with structure-level parallelism (mirrors src/main.rs:375,439: one
+    structure per worker, the kernel sequential inside); same inputs, wall clock, best of three after a warm-up.
+    The sample is every k-th structure of the rank's list (k = 1: all of it), so it has the list's size mix -
+    not its largest structures.  Returns the bench-line object, the sampled structure indices and the oracle's
+    per-atom values of the all-threads sample (concatenated in that order)."""
+    import numpy as np
+    import bench_workloads as bw
     from oracle import pyoracle as po
     threads = min(po.max_threads(), os.cpu_count() or 1)
 
-    def run(n_struct, n_threads):
-        e = int(batch.structure_offsets[n_struct])
+    def run(b, n_threads):
         t0 = time.perf_counter()
-        v = po.calculate_sasa_batch(batch.x[:e], batch.y[:e], batch.z[:e], batch.radius[:e],
-                                    batch.ids[:e], batch.structure_offsets[:n_struct + 1], PROBE,
+        v = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE,
                                     n_points, 8, threads=n_threads)
         return time.perf_counter() - t0, v
 
-    def leg(n_threads, seconds, floor):
-        probe_n = min(batch.n_structures, floor)
-        run(min(probe_n, 8), n_threads)  # warm up the thread pool and page in the library
-        t_probe, v = run(probe_n, n_threads)
-        n = int(min(batch.n_structures, max(probe_n, probe_n * seconds / max(t_probe, 1e-6))))
-        best, v = (t_probe, v) if n == probe_n else run(n, n_threads)
+    def leg(n_threads, seconds):
+        # a probe on every 64th structure sizes the sample for about `seconds` per run
+        probe = bw.select(batch, np.arange(0, batch.n_structures, 64))
+        run(probe, n_threads)  # warm up the thread pool, the workers' arenas and the library
+        t_probe, _ = run(probe, n_threads)
+        t_all = t_probe * batch.n_atoms / max(probe.n_atoms, 1)  # the whole list at the probe's rate
+        k = max(1, int(round(t_all / max(seconds, 1e-3))))
+        idx = np.arange(0, batch.n_structures, k)
+        b = bw.select(batch, idx)
+        best, v = run(b, n_threads)
         for _ in range(2):
-            t, v = run(n, n_threads)
+            t, v = run(b, n_threads)
             best = min(best, t)
-        return n, best, v
+        return idx, b, best, v
 
-    # about a third of the budget per all-cores run, a fifth of that per one-thread run
-    n, t, v = leg(threads, target_seconds / 3.0, max(threads * 4, 16))
-    n1, t1, _ = leg(1, target_seconds / 15.0, 4)
-    atoms = int(batch.structure_offsets[n])
-    line = {"value": round(n / t, 3), "unit": "structures/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} of {batch.n_structures} structures ({atoms} atoms) of rank 0's "
-                      f"workload, {n_points} points, oracle/sasa_oracle.c with OpenMP over "
-                      f"structures, best of 3 runs, {t:.2f} s wall",
-            "one_thread": {"value": round(n1 / t1, 3), "unit": "structures/s", "cores": 1,
-                           "sample": f"first {n1} structures ({int(batch.structure_offsets[n1])} atoms), "
-                                     f"best of 3 runs, {t1:.2f} s wall"}}
-    return line, v, n
+    # about a third of the budget per all-threads run, a fifth of that per one-thread run
+    idx, b, t, v = leg(threads, target_seconds / 3.0)
+    idx1, b1, t1, _ = leg(1, target_seconds / 15.0)
+    every = int(idx[1] - idx[0]) if len(idx) > 1 else 1
+    every1 = int(idx1[1] - idx1[0]) if len(idx1) > 1 else 1
+    one = {"value": round(b1.n_structures / t1, 3), "unit": "structures/s", "cores": 1,
+           "atoms_per_s": round(b1.n_atoms / t1, 1),
+           "sample": f"every k-th structure of the list, k = {every1}: {b1.n_structures} structures ({b1.n_atoms} atoms), "
+                     f"best of 3 runs, {t1:.2f} s wall"}
+    line = {"value": round(b.n_structures / t, 3), "unit": "structures/s", "cores": threads, "kind": "port",
+            "threads_used": threads, "physical_cores": physical_cores(),
+            "atoms_per_s": round(b.n_atoms / t, 1),
+            "speedup_over_one_thread": round((b.n_atoms / t) / (b1.n_atoms / t1), 2),
+            "sample": (f"all {b.n_structures}" if every == 1 else f"every k-th structure of the list, k = {every}: {b.n_structures} of {batch.n_structures}")
+                      + f" structures ({b.n_atoms} atoms) of rank 0's workload, {n_points} points, "
+                        f"oracle/sasa_oracle.c with OpenMP over structures (one per worker, per-worker scratch arenas), "
+                        f"best of 3 runs, {t:.2f} s wall",
+            "one_thread": one}
+    return line, idx, v
 
 
-def parity(batch, n_struct, want_atoms, got_atoms, got_res):
-    """GPU results of the timed run against the oracle's on the CPU sample: atoms and residues."""
+def parity(batch, idx, want_atoms, got_atoms, got_res):
+    """GPU results of the timed run against the oracle's on the CPU sample (structures `idx`): atoms and residues."""
     import numpy as np
     from oracle import pyoracle as po
-    e = int(batch.structure_offsets[n_struct])
-    ga = got_atoms[:e]
-    n_res = int(np.searchsorted(batch.residue_offsets, e, side="right") - 1)
-    want_res = po.residue_sums(want_atoms, batch.residue_offsets[:n_res + 1])
-    d = np.abs(ga - want_atoms)
-    dr = np.abs(got_res[:n_res] - want_res)
-    return {"max_abs": float(d.max()) if e else 0.0, "n_mismatch": int(np.count_nonzero(ga != want_atoms)),
-            "atoms_compared": e, "residue_max_abs": float(dr.max()) if n_res else 0.0,
-            "residue_n_mismatch": int(np.count_nonzero(got_res[:n_res] != want_res)),
-            "residues_compared": n_res, "tolerance": 1e-4,
+    so = batch.structure_offsets.astype(np.int64)
+    ro = batch.residue_offsets.astype(np.int64)
+    n_bad = n_cmp = r_bad = r_cmp = 0
+    max_abs = r_max = 0.0
+    pos = 0
+    for s in idx:
+        b, e = int(so[s]), int(so[s + 1])
+        want = want_atoms[pos:pos + (e - b)]
+        pos += e - b
+        got = got_atoms[b:e]
+        n_cmp += e - b
+        n_bad += int(np.count_nonzero(got != want))
+        if e > b:
+            max_abs = max(max_abs, float(np.abs(got - want).max()))
+        r0, r1 = int(np.searchsorted(ro, b)), int(np.searchsorted(ro, e))
+        if r1 > r0:
+            want_res = po.residue_sums(want, (ro[r0:r1 + 1] - b).astype(np.uint32))
+            r_cmp += r1 - r0
+            r_bad += int(np.count_nonzero(got_res[r0:r1] != want_res))
+            r_max = max(r_max, float(np.abs(got_res[r0:r1] - want_res).max()))
+    return {"max_abs": max_abs, "n_mismatch": n_bad, "atoms_compared": n_cmp, "residue_max_abs": r_max,
+            "residue_n_mismatch": r_bad, "residues_compared": r_cmp, "tolerance": 1e-4,
             "against": "oracle/sasa_oracle.c on the cpu_baseline sample"}
 
 
@@ -493,8 +532,8 @@ def main():
         if weak:
             line["weak_scaling"] = weak
         if args.cpu_seconds > 0:  # (rank 0, on its own shard at N > 1)
-            line["cpu_baseline"], want, n_cmp = cpu_baseline(batch, n_points, args.cpu_seconds)
-            line["parity"] = parity(batch, n_cmp, want, got_atoms, got_res)
+            line["cpu_baseline"], cmp_idx, want = cpu_baseline(batch, n_points, args.cpu_seconds)
+            line["parity"] = parity(batch, cmp_idx, want, got_atoms, got_res)
         print(json.dumps(line), flush=True)
 
     ctx.close()

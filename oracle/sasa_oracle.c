@@ -47,6 +47,99 @@ static int32_t f32_as_i32(float v)
 }
 
 /* ------------------------------------------------------------------------ */
+/* Scratch memory.  A single call allocates and frees with malloc like the    */
+/* reference's Vecs.  The batch path (one structure per worker, main.rs:375)   */
+/* gives every worker thread an arena that it rewinds between structures:      */
+/* the grid, the 640-byte-per-atom neighbour slab and the list headers of a    */
+/* structure are megabytes, and 128 threads that mmap / fault / munmap them    */
+/* per structure spend their time under the process's one memory-map lock      */
+/* instead of in the algorithm (round 3: 11x on 128 threads).  Results do not  */
+/* depend on where scratch lives.                                             */
+typedef struct arena_block {
+    struct arena_block *next;
+    size_t cap, used;
+} arena_block_t;
+
+static _Thread_local arena_block_t *tl_arena;
+static _Thread_local int tl_arena_on;
+
+static void *xmalloc(size_t bytes)
+{
+    if (!tl_arena_on)
+        return malloc(bytes);
+    const size_t hdr = (sizeof(arena_block_t) + 63u) & ~(size_t)63u;
+    bytes = (bytes + 63u) & ~(size_t)63u;
+    arena_block_t *b = tl_arena;
+    if (!b || b->cap - b->used < bytes) {
+        size_t cap = b ? 2 * b->cap : ((size_t)8 << 20);
+        if (cap < bytes)
+            cap = bytes;
+        arena_block_t *nb = aligned_alloc(64, hdr + cap);
+        if (!nb)
+            return NULL;
+        nb->next = b;
+        nb->cap = cap;
+        nb->used = 0;
+        tl_arena = b = nb;
+    }
+    void *p = (char *)b + hdr + b->used;
+    b->used += bytes;
+    return p;
+}
+
+static void *xcalloc(size_t n, size_t size)
+{
+    void *p = xmalloc(n * size);
+    if (p)
+        memset(p, 0, n * size);
+    return p;
+}
+
+static void xfree(void *p)
+{
+    if (!tl_arena_on)
+        free(p);
+}
+
+/* grow a buffer whose old contents are not needed */
+static void *xregrow(void *old, size_t bytes)
+{
+    if (!tl_arena_on)
+        return realloc(old, bytes);
+    return xmalloc(bytes);
+}
+
+static void arena_release(void)
+{
+    while (tl_arena) {
+        arena_block_t *n = tl_arena->next;
+        free(tl_arena);
+        tl_arena = n;
+    }
+}
+
+/* rewind; several blocks are replaced by one of their total size, so the next structure of that size fits */
+static void arena_rewind(void)
+{
+    if (tl_arena && tl_arena->next) {
+        size_t total = 0;
+        for (arena_block_t *b = tl_arena; b; b = b->next)
+            total += b->cap;
+        arena_release();
+        const size_t hdr = (sizeof(arena_block_t) + 63u) & ~(size_t)63u;
+        arena_block_t *nb = aligned_alloc(64, hdr + total);
+        if (nb) {
+            nb->next = NULL;
+            nb->cap = total;
+            nb->used = 0;
+            tl_arena = nb;
+        }
+    } else if (tl_arena) {
+        tl_arena->used = 0;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* src/lib.rs:43-66 generate_sphere_points                                   */
 /* ------------------------------------------------------------------------ */
 void oracle_generate_sphere_points(size_t n_points, float *x, float *y, float *z)
@@ -103,13 +196,13 @@ static inline size_t cell_index(float x, float y, float z, const float min_b[3],
 
 static void grid_free(grid_t *g)
 {
-    free(g->atom_indices);
-    free(g->px);
-    free(g->py);
-    free(g->pz);
-    free(g->radii);
-    free(g->cell_starts);
-    free(g->half_shell);
+    xfree(g->atom_indices);
+    xfree(g->px);
+    xfree(g->py);
+    xfree(g->pz);
+    xfree(g->radii);
+    xfree(g->cell_starts);
+    xfree(g->half_shell);
     memset(g, 0, sizeof *g);
 }
 
@@ -142,7 +235,7 @@ static int grid_new(grid_t *g, const atoms_t *a, float cell_size, float max_sear
     /* :47-50, :174-192 half-shell offsets */
     int32_t extent = f32_as_i32(ceilf(max_search_radius / cell_size));
     size_t side = (size_t)(2 * extent + 1);
-    g->half_shell = malloc(sizeof(int32_t[3]) * side * side * side);
+    g->half_shell = xmalloc(sizeof(int32_t[3]) * side * side * side);
     if (!g->half_shell)
         return -1;
     for (int32_t dz = -extent; dz <= extent; dz++)
@@ -158,18 +251,18 @@ static int grid_new(grid_t *g, const atoms_t *a, float cell_size, float max_sear
             }
 
     /* :53-68 counts + exclusive prefix */
-    g->cell_starts = calloc(g->num_cells + 1, sizeof(uint32_t));
-    uint32_t *write_pos = malloc(sizeof(uint32_t) * (g->num_cells ? g->num_cells : 1));
-    uint32_t *cell_of = malloc(sizeof(uint32_t) * (n ? n : 1));
-    g->atom_indices = malloc(sizeof(uint32_t) * (n ? n : 1));
-    g->px = malloc(sizeof(float) * (n ? n : 1));
-    g->py = malloc(sizeof(float) * (n ? n : 1));
-    g->pz = malloc(sizeof(float) * (n ? n : 1));
-    g->radii = malloc(sizeof(float) * (n ? n : 1));
+    g->cell_starts = xcalloc(g->num_cells + 1, sizeof(uint32_t));
+    uint32_t *write_pos = xmalloc(sizeof(uint32_t) * (g->num_cells ? g->num_cells : 1));
+    uint32_t *cell_of = xmalloc(sizeof(uint32_t) * (n ? n : 1));
+    g->atom_indices = xmalloc(sizeof(uint32_t) * (n ? n : 1));
+    g->px = xmalloc(sizeof(float) * (n ? n : 1));
+    g->py = xmalloc(sizeof(float) * (n ? n : 1));
+    g->pz = xmalloc(sizeof(float) * (n ? n : 1));
+    g->radii = xmalloc(sizeof(float) * (n ? n : 1));
     if (!g->cell_starts || !write_pos || !cell_of || !g->atom_indices || !g->px || !g->py ||
         !g->pz || !g->radii) {
-        free(write_pos);
-        free(cell_of);
+        xfree(write_pos);
+        xfree(cell_of);
         grid_free(g);
         return -1;
     }
@@ -190,8 +283,8 @@ static int grid_new(grid_t *g, const atoms_t *a, float cell_size, float max_sear
         g->pz[wp] = a->z[i];
         g->radii[wp] = a->r[i];
     }
-    free(write_pos);
-    free(cell_of);
+    xfree(write_pos);
+    xfree(cell_of);
     return 0;
 }
 
@@ -206,12 +299,12 @@ static inline int nvec_push(nvec_t *v, uint32_t idx, float thr)
 {
     if (v->len == v->cap) {
         uint32_t ncap = v->cap * 2;
-        oracle_neighbor_t *np = malloc(sizeof(oracle_neighbor_t) * ncap);
+        oracle_neighbor_t *np = xmalloc(sizeof(oracle_neighbor_t) * ncap);
         if (!np)
             return -1;
         memcpy(np, v->p, sizeof(oracle_neighbor_t) * v->len);
         if (v->owned)
-            free(v->p);
+            xfree(v->p);
         v->p = np;
         v->cap = ncap;
         v->owned = 1;
@@ -283,7 +376,7 @@ static int sort_neighbors(const atoms_t *a, size_t center_idx, nvec_t *v, keyed_
     if (v->len <= 1)
         return 0;
     if (*scratch_cap < v->len) {
-        keyed_t *ns = realloc(*scratch, sizeof(keyed_t) * v->len * 2);
+        keyed_t *ns = xregrow(*scratch, sizeof(keyed_t) * v->len * 2);
         if (!ns)
             return -1;
         *scratch = ns;
@@ -322,11 +415,11 @@ static int build_all_neighbor_lists(const grid_t *g, const atoms_t *a, float pro
 {
     size_t n = a->n;
     const uint32_t INITIAL_CAP = 80;                                     /* :213 */
-    nvec_t *lists = malloc(sizeof(nvec_t) * (n ? n : 1));
-    oracle_neighbor_t *slab = malloc(sizeof(oracle_neighbor_t) * INITIAL_CAP * (n ? n : 1));
+    nvec_t *lists = xmalloc(sizeof(nvec_t) * (n ? n : 1));
+    oracle_neighbor_t *slab = xmalloc(sizeof(oracle_neighbor_t) * INITIAL_CAP * (n ? n : 1));
     if (!lists || !slab) {
-        free(lists);
-        free(slab);
+        xfree(lists);
+        xfree(slab);
         return -1;
     }
     for (size_t i = 0; i < n; i++) {
@@ -374,13 +467,13 @@ static int build_all_neighbor_lists(const grid_t *g, const atoms_t *a, float pro
     size_t scratch_cap = 0;
     for (size_t i = 0; i < n && !rc; i++)                                /* :275 */
         rc = sort_neighbors(a, i, &lists[i], &scratch, &scratch_cap);
-    free(scratch);
+    xfree(scratch);
     if (rc) {
         for (size_t i = 0; i < n; i++)
             if (lists[i].owned)
-                free(lists[i].p);
-        free(lists);
-        free(slab);
+                xfree(lists[i].p);
+        xfree(lists);
+        xfree(slab);
         return -1;
     }
     *out_lists = lists;
@@ -393,9 +486,9 @@ static void free_lists(nvec_t *lists, oracle_neighbor_t *slab, size_t n)
     if (lists)
         for (size_t i = 0; i < n; i++)
             if (lists[i].owned)
-                free(lists[i].p);
-    free(lists);
-    free(slab);
+                xfree(lists[i].p);
+    xfree(lists);
+    xfree(slab);
 }
 
 /* src/lib.rs:69-84 precompute_neighbors */
@@ -434,11 +527,11 @@ int oracle_neighbor_lists(const float *x, const float *y, const float *z, const 
     if (rc)
         return -1;
     out->n_atoms = n;
-    out->offsets = malloc(sizeof(size_t) * (n + 1));
+    out->offsets = xmalloc(sizeof(size_t) * (n + 1));
     size_t total = 0;
     for (size_t i = 0; i < n; i++)
         total += lists[i].len;
-    out->entries = malloc(sizeof(oracle_neighbor_t) * (total ? total : 1));
+    out->entries = xmalloc(sizeof(oracle_neighbor_t) * (total ? total : 1));
     if (!out->offsets || !out->entries) {
         free_lists(lists, slab, n);
         oracle_neighbor_lists_free(out);
@@ -457,8 +550,8 @@ int oracle_neighbor_lists(const float *x, const float *y, const float *z, const 
 
 void oracle_neighbor_lists_free(oracle_neighbor_lists_t *l)
 {
-    free(l->offsets);
-    free(l->entries);
+    xfree(l->offsets);
+    xfree(l->entries);
     memset(l, 0, sizeof *l);
 }
 
@@ -634,13 +727,13 @@ int oracle_calculate_sasa_internal_mt(const float *x, const float *y, const floa
     if (!kern)
         return -1;
     atoms_t a = {x, y, z, radius, id, n};
-    float *sp = malloc(sizeof(float) * 3 * (n_points ? n_points : 1));
+    float *sp = xmalloc(sizeof(float) * 3 * (n_points ? n_points : 1));
     if (!sp)
         return -1;
     oracle_generate_sphere_points(n_points, sp, sp + n_points, sp + 2 * n_points); /* :257 */
     int rc = calculate_with_lattice(&a, probe_radius, n_points, sp, sp + n_points,
                                     sp + 2 * n_points, kern, out_sasa, out_points, out_k, threads);
-    free(sp);
+    xfree(sp);
     return rc;
 }
 
@@ -657,24 +750,31 @@ int oracle_calculate_sasa_batch(const float *x, const float *y, const float *z,
     if (threads < 1)
         threads = oracle_max_threads();
     /* each worker regenerates the lattice per structure exactly as the
-     * reference does per calculate_sasa_internal call (lib.rs:257) */
-#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
-    for (long s = 0; s < (long)n_structures; s++) {
-        size_t b = offsets[s], e = offsets[s + 1];
-        atoms_t a = {x + b, y + b, z + b, radius + b, id ? id + b : NULL, e - b};
-        float *sp = malloc(sizeof(float) * 3 * (n_points ? n_points : 1));
-        if (!sp) {
+     * reference does per calculate_sasa_internal call (lib.rs:257); its scratch
+     * (grid, neighbour slab, lattice) lives in the worker's arena, rewound per structure */
+#pragma omp parallel num_threads(threads)
+    {
+        tl_arena_on = 1;
+#pragma omp for schedule(dynamic, 1)
+        for (long s = 0; s < (long)n_structures; s++) {
+            arena_rewind();
+            size_t b = offsets[s], e = offsets[s + 1];
+            atoms_t a = {x + b, y + b, z + b, radius + b, id ? id + b : NULL, e - b};
+            float *sp = xmalloc(sizeof(float) * 3 * (n_points ? n_points : 1));
+            if (!sp) {
 #pragma omp atomic write
-            failed = 1;
-            continue;
-        }
-        oracle_generate_sphere_points(n_points, sp, sp + n_points, sp + 2 * n_points);
-        if (calculate_with_lattice(&a, probe_radius, n_points, sp, sp + n_points,
-                                   sp + 2 * n_points, kern, out_sasa + b, NULL, NULL, 1)) {
+                failed = 1;
+                continue;
+            }
+            oracle_generate_sphere_points(n_points, sp, sp + n_points, sp + 2 * n_points);
+            if (calculate_with_lattice(&a, probe_radius, n_points, sp, sp + n_points,
+                                       sp + 2 * n_points, kern, out_sasa + b, NULL, NULL, 1)) {
 #pragma omp atomic write
-            failed = 1;
+                failed = 1;
+            }
         }
-        free(sp);
+        tl_arena_on = 0;
+        arena_release();
     }
     return failed ? -1 : 0;
 }
