@@ -47,14 +47,56 @@ void generate_sphere_points(size_t n, float *x, float *y, float *z)
     }
 }
 
+// ---- sphere points in patches (point counts above 128 only) ----
+// Every kernel only COUNTS points, so the order of the points that share a rule is free.  With many points the
+// matrix-core kernel first tests whole patches of 16 points against the nearest candidates (one candidate whose
+// cap holds the patch kills all 16: occlusion_mx.inc); for that the fused-rule points [0, n_fused) are reordered so
+// that every aligned run of 16 is a compact patch of the sphere (recursive bisection along the widest axis, left
+// halves in multiples of 16).  The remainder points keep their places behind them.
+static void bisect_points(std::vector<uint32_t> &idx, size_t lo, size_t hi, const float *x, const float *y, const float *z)
+{
+    const size_t n = hi - lo;
+    if (n <= 16) return;
+    float mn[3] = {2.f, 2.f, 2.f}, mx[3] = {-2.f, -2.f, -2.f};
+    for (size_t i = lo; i < hi; i++) {
+        const float c[3] = {x[idx[i]], y[idx[i]], z[idx[i]]};
+        for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], c[k]); mx[k] = std::max(mx[k], c[k]); }
+    }
+    int ax = 0;
+    for (int k = 1; k < 3; k++)
+        if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+    const float *c = ax == 0 ? x : ax == 1 ? y : z;
+    std::sort(idx.begin() + (long)lo, idx.begin() + (long)hi,
+              [c](uint32_t a, uint32_t b) { return c[a] != c[b] ? c[a] < c[b] : a < b; });
+    const size_t left = ((n + 15) / 16 / 2) * 16;
+    bisect_points(idx, lo, lo + left, x, y, z);
+    bisect_points(idx, lo + left, hi, x, y, z);
+}
+
+static uint16_t f16_bits(_Float16 h)
+{
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+// smallest f16 >= v (v finite, non-negative, below the f16 range's end)
+static uint16_t f16_round_up(float v)
+{
+    _Float16 h = (_Float16)v;
+    uint16_t u = f16_bits(h);
+    if ((float)h < v) u++;  // next representable value (positive numbers: the bit pattern is monotone)
+    return u;
+}
+
 struct DeviceBuffer {
     void *p = nullptr;
     size_t cap = 0;
 };
 
 struct LatticeEntry {
-    float *d = nullptr;  // x | y | z, each `padded` floats
+    float *d = nullptr;  // x | y | z, each `padded` floats, | (x, y, z, 0) records | patch table (16 bytes per patch)
     uint32_t padded = 0;
+    uint32_t n_patches = 0;  // 0: the points are in the reference's order and have no patch table
 };
 
 struct Pending {
@@ -361,7 +403,7 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
         // the cache holds the few point counts a program uses; a sweep over many counts must not
         // pin 28 bytes per point per count forever
         size_t cached_bytes = 0;
-        for (const auto &kv : ctx->lattices) cached_bytes += 7 * sizeof(float) * (size_t)kv.second.padded;
+        for (const auto &kv : ctx->lattices) cached_bytes += 7 * sizeof(float) * (size_t)kv.second.padded + 16 * (size_t)kv.second.n_patches;
         if (ctx->lattices.size() >= 16 || cached_bytes > (64u << 20)) {
             RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (const Pending &pd : ctx->pending)
@@ -371,8 +413,41 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
             ctx->lattices.clear();
         }
         const uint32_t padded = (uint32_t)((n_points + 63) / 64 * 64);
-        std::vector<float> h(7 * (size_t)padded, 0.0f);  // x | y | z | (x, y, z, 0) records
+        const uint32_t n_patches = n_points > 128 ? (uint32_t)((n_points + 15) / 16) : 0u;
+        const uint32_t patches_padded = (n_patches + 63u) / 64u * 64u;
+        std::vector<float> h(7 * (size_t)padded + 4 * (size_t)patches_padded, 0.0f);  // x | y | z | (x, y, z, 0) records | patches
         generate_sphere_points(n_points, h.data(), h.data() + padded, h.data() + 2 * (size_t)padded);
+        if (n_patches) {
+            // compact patches: permute the fused-rule points (see bisect_points), then one table entry per patch:
+            // (cz, cy | cx, -1 | eps, 0 | 0, 0) as f16 - centre c (unit, rounded to nearest) and eps >= the largest
+            // distance from c to a point of the patch (+ the centre's rounding), rounded up
+            const size_t n_fused = n_points - n_points % (size_t)ctx->simd_width;
+            std::vector<uint32_t> idx(n_fused);
+            for (size_t i = 0; i < n_fused; i++) idx[i] = (uint32_t)i;
+            float *px = h.data(), *py = h.data() + padded, *pz = h.data() + 2 * (size_t)padded;
+            bisect_points(idx, 0, n_fused, px, py, pz);
+            std::vector<float> t(3 * n_fused);
+            for (size_t i = 0; i < n_fused; i++) { t[3 * i] = px[idx[i]]; t[3 * i + 1] = py[idx[i]]; t[3 * i + 2] = pz[idx[i]]; }
+            for (size_t i = 0; i < n_fused; i++) { px[i] = t[3 * i]; py[i] = t[3 * i + 1]; pz[i] = t[3 * i + 2]; }
+            uint16_t *pt = reinterpret_cast<uint16_t *>(h.data() + 7 * (size_t)padded);
+            for (uint32_t k = 0; k < n_patches; k++) {
+                const size_t b = 16 * (size_t)k, e = std::min(b + 16, n_points);
+                double c[3] = {0, 0, 0};
+                for (size_t i = b; i < e; i++) { c[0] += px[i]; c[1] += py[i]; c[2] += pz[i]; }
+                const double len = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+                _Float16 c16[3];
+                for (int q = 0; q < 3; q++) c16[q] = (_Float16)(float)(len > 0 ? c[q] / len : (q == 2 ? 1.0 : 0.0));
+                double eps = 0;  // against the centre the kernel will actually use (the f16 one)
+                for (size_t i = b; i < e; i++) {
+                    const double dx = px[i] - (double)(float)c16[0], dy = py[i] - (double)(float)c16[1], dz = pz[i] - (double)(float)c16[2];
+                    eps = std::max(eps, std::sqrt(dx * dx + dy * dy + dz * dz));
+                }
+                uint16_t *en = pt + 8 * (size_t)k;
+                en[0] = f16_bits(c16[2]); en[1] = f16_bits(c16[1]); en[2] = f16_bits(c16[0]); en[3] = f16_bits((_Float16)-1.0f);
+                en[4] = f16_round_up((float)(eps * 1.001 + 1e-4)); en[5] = en[6] = en[7] = 0;
+            }
+            // (entries of patches that do not exist: centre 0, -1 -> 0, eps 0: all zero, never looked at)
+        }
         for (size_t i = 0; i < n_points; i++) {
             float *r4 = h.data() + 3 * (size_t)padded + 4 * i;
             r4[0] = h[i];
@@ -381,6 +456,7 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
         }
         LatticeEntry e;
         e.padded = padded;
+        e.n_patches = n_patches;
         RS_HIP(ctx, hipMalloc((void **)&e.d, h.size() * sizeof(float)));
         hipError_t err = hipMemcpy(e.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
         if (err != hipSuccess) {
@@ -393,6 +469,8 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
     out->y = it->second.d + it->second.padded;
     out->z = it->second.d + 2 * (size_t)it->second.padded;
     out->xyz4 = (const float4 *)(it->second.d + 3 * (size_t)it->second.padded);
+    out->patches = it->second.n_patches ? (const uint4 *)(it->second.d + 7 * (size_t)it->second.padded) : nullptr;
+    out->n_patches = it->second.n_patches;
     out->n_points = (uint32_t)n_points;
     out->n_fused = (uint32_t)(n_points - n_points % (size_t)ctx->simd_width);
     return RSASA_OK;
@@ -971,7 +1049,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
         }
         if (!finite || !small_grid(mn, mx, mr, probe, so[s + 1] - so[s], &grids[s])) return kNotSmall;
         grids[s].atom_begin = so[s];
-        grids[s].odd_radii = odd_r ? 1u : 0u;
+        grids[s].odd_radii = (odd_r ? 1u : 0u) | (grid_group_shift(grids[s].n_atoms, grids[s].n_cells) << 8);
         grids[s].sorted_base = so[s];
         grids[s].cell_base = (uint32_t)total_cells;
         total_cells += lds_cell_slots(grids[s].n_cells);

@@ -21,8 +21,9 @@ struct StructGrid {
     uint32_t sorted_base;          // first position of the structure in the cell-sorted arrays
     uint32_t in_lds;               // 1: binned by k_sort_window (fewer than 65536 atoms; 16-bit cell starts relative
                                    // to sorted_base), 0: by the batch-wide kernels (32-bit absolute cell starts)
-    uint32_t odd_radii;            // 1: some radius of the structure lies outside [0, 64] or is NaN (the matrix-core
-                                   // occlusion kernel leaves such structures to the general kernel)
+    uint32_t odd_radii;            // bit 0: some radius of the structure lies outside [0, 64] or is NaN (the matrix-core
+                                   // occlusion kernel leaves such structures to the general kernel);
+                                   // bits 8..9: log2 of the x-cell block its atom groups share (grid_group_shift)
 };
 static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
 
@@ -62,6 +63,8 @@ static_assert(sizeof(BatchStatus) == 48, "BatchStatus layout");
 struct Lattice {
     const float *x, *y, *z;  // device SoA, padded with zeros to a multiple of 64 entries
     const float4 *xyz4;      // the same points as (x, y, z, 0) records
+    const uint4 *patches;    // point counts above 128: one entry per aligned run of 16 points, f16 (cz, cy | cx, -1 | eps, 0 | 0, 0)
+    uint32_t n_patches;      // (see context.cpp bisect_points, occlusion_mx.inc); else null / 0
     uint32_t n_points;
     uint32_t n_fused;        // points [0, n_fused) use the fused-FMA `<` rule (lib.rs:143-146);
                              // the rest the scalar remainder rule (lib.rs:185-186,206-207)
@@ -166,6 +169,15 @@ constexpr uint32_t kLdsMaxAtoms = 65536;  // structures with fewer atoms are bin
 
 // 16-bit entries a structure of n_cells cells takes in the cell array: its cells, the end marker,
 // padding to whole 16-byte vectors.
+// k_occlusion_mx groups atoms of one cell row whose x cells fall in the same aligned block of 2^shift cells; the group
+// shares the union of the 25 x-runs around it, (2^shift + 4) cells long, which must hold at most 256 atoms or the group
+// is narrowed (and the runs looked up again).  Where atoms fill their grid - 1.5 per cell in a dense medium - a block
+// of 8 cells never fits: start from the width that does.  (A heuristic: it changes the kernel's speed, not its results.)
+__host__ __device__ inline uint32_t grid_group_shift(uint32_t n_atoms, uint32_t n_cells)
+{
+    const float per_cell = (float)n_atoms / (float)(n_cells ? n_cells : 1u);
+    return per_cell >= 1.0f ? 0u : per_cell >= 0.6f ? 1u : per_cell >= 0.3f ? 2u : 3u;
+}
 __host__ __device__ constexpr uint32_t lds_cell_slots(uint32_t n_cells) { return (n_cells + 1u + 7u) & ~7u; }
 __host__ __device__ constexpr uint32_t grid_windows(uint32_t n_cells) { return (n_cells + kWindowCells - 1u) / kWindowCells; }
 

@@ -130,7 +130,7 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
     // 16-bit LDS counters and positions: structures with fewer than 65536 atoms are binned in LDS,
     // one k_sort_window workgroup per window of kWindowCells cells; the others by the batch-wide kernels
     g.in_lds = a.n_atoms < kLdsMaxAtoms ? 1u : 0u;
-    g.odd_radii = a.odd_radii != 0 ? 1u : 0u;
+    g.odd_radii = (a.odd_radii != 0 ? 1u : 0u) | (grid_group_shift(a.n_atoms, (uint32_t)nc) << 8);
     return g;
 }
 

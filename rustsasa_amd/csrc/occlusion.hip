@@ -88,6 +88,22 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
     else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
 }
 
+constexpr uint32_t kMxLdsBudget = 157u * 1024u;  // what workgroups of k_occlusion_mx can share of a CU's 160 KB (see launch_occlusion)
+
+// static LDS of the many-point instantiations per wave (the same for every NW: the lists are per wave)
+uint32_t mx_multi_lds_per_wave()
+{
+    static uint32_t bytes = 0;
+    if (!bytes) {
+        hipFuncAttributes at{};
+        if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_occlusion_mx<8, true, true, true, 4>)) == hipSuccess && at.sharedSizeBytes)
+            bytes = (uint32_t)at.sharedSizeBytes / 4u;
+        else
+            bytes = 3584u;
+    }
+    return bytes;
+}
+
 void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream_t stream, const OccArgs3 &a3)
 {
     if (has_id && rem) launch_fast2<true, true>(half1, n_blocks, stream, a3);
@@ -156,16 +172,31 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
             const bool has_id = b.id != nullptr;
             // (+ 16 zero entries of the f32 table: the column that pads phase B's last round)
-            const uint32_t table = 24u * 128u * cdiv(lat.n_points, 128u) + 256u;  // (groups of 128 points)
             if (lat.n_points <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u + 256u, stream, a3);
             else if (lat.n_points <= 112u) launch_mx<7, false, 4>(has_id, rem, b.n_atoms, 24u * 112u + 256u, stream, a3);
             else if (lat.n_points <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u + 256u, stream, a3);
-            // more points: the waves per workgroup that keep most waves on a CU (160 KB of LDS: the
-            // table once per workgroup, ~3.2 KB per wave).  Multiples of four only: 9 or 14 waves per
-            // workgroup spread unevenly over the four SIMDs and measured 18 % slower.
-            else if (table <= 8192u + 256u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, table, stream, a3);
-            else if (table <= 24576u + 256u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, table, stream, a3);   // 3 x 8 waves
-            else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, table, stream, a3);                        // 2 x 12 waves
+            else {
+                // More points: whole tiles of 16 points in the two tables, the patch table behind them (16 bytes per tile,
+                // whole blocks of 64, and a zero entry).  The tables are per workgroup, the lists per wave (3.4 KB): pick
+                // the waves per workgroup - 4, 8 or 12; 9 or 14 spread unevenly over the four SIMDs and measured 18 %
+                // slower - that keeps most waves on a CU.  Its 160 KB of LDS are not all there for the taking: three
+                // workgroups of 52 240 bytes ran side by side, three of 53 776 did not, so the budget is set to 157 KB.  With
+                // equal wave counts the smaller workgroup wins (960 points: 3 x 8 waves 0.87 ms, 2 x 12 waves 0.93 ms).
+                const uint32_t dyn = 24u * 16u * cdiv(lat.n_points, 16u) + 256u + 16u * (cdiv(cdiv(lat.n_points, 16u), 64u) * 64u) + 16u;
+                const uint32_t per_wave = mx_multi_lds_per_wave();
+                uint32_t best_nw = 4u, best_waves = 0u;
+                for (uint32_t nw = 4u; nw <= 12u; nw += 4u) {
+                    const uint32_t total = per_wave * nw + dyn;
+                    const uint32_t waves = min(nw * (kMxLdsBudget / total), nw >= 8u ? 24u : 28u);  // (72 / 80 registers: 7 / 6 waves per SIMD)
+                    if (waves > best_waves) { best_nw = nw; best_waves = waves; }
+                }
+#ifdef MX_FORCE_NW  // experiments only
+                best_nw = MX_FORCE_NW;
+#endif
+                if (best_nw == 4u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, dyn, stream, a3);
+                else if (best_nw == 8u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, dyn, stream, a3);
+                else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, dyn, stream, a3);
+            }
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }
