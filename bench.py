@@ -66,6 +66,10 @@ def parse_args(argv=None):
                    help="one GPU only: run rank 0's shard of an M-way strong-scaling split (what each of M GPUs would get)")
     p.add_argument("--weak-steps", type=int, default=5,
                    help="timed steps of the secondary weak-scaling measurement at N > 1 (0 disables it)")
+    p.add_argument("--config5-steps", type=int, default=30,
+                   help="timed steps of the secondary 1M-atom / 960-point measurement (BASELINE.json configs[4]; 0 = skip)")
+    p.add_argument("--files", type=int, default=1000,
+                   help="files of the secondary directory-mode measurement (files on /dev/shm -> residue values; 0 = skip)")
     p.add_argument("--no-ids", action="store_true", help="pass id = NULL (all atoms distinct)")
     p.add_argument("--dry-run", action="store_true",
                    help="CPU only (gloo): launcher, sharding and aggregation without any GPU work")
@@ -82,6 +86,49 @@ def self_launch(args):
            f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' -> {0, 1, 2, 3, 8, 10, 11}"""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def numa_bind(bdf, sysfs="/sys"):
+    """Pins this process - and every thread it starts from here on: the library's coding threads, the pinned
+    allocations' first touch - to the CPUs of the NUMA node the GPU `bdf` (PCI address) hangs off.  No exec, no
+    numactl hop (a process that has initialised the GPU must not exec).  Returns what it did for the bench line."""
+    info = {"numa_node": None, "cpus": None, "cpu_list": None, "gpu_pci": bdf}
+    if not bdf:
+        return info
+    base = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read())
+        cpulist = open(os.path.join(base, "local_cpulist")).read().strip()
+    except (OSError, ValueError):
+        return info
+    info["numa_node"] = node
+    if node < 0 or not cpulist:
+        return info  # a single-node machine (or a VM that hides the topology): nothing to pin
+    cpus = parse_cpulist(cpulist) & os.sched_getaffinity(0)
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+        info["cpus"], info["cpu_list"] = len(cpus), cpulist
+    return info
+
+
+def gpu_pci_address(torch, index):
+    """PCI address of torch's device `index` (after HIP_VISIBLE_DEVICES remapping), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        return f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:
+        return None
 
 
 def physical_cores():
@@ -289,6 +336,89 @@ def timed(dist, steps, fn):
     return time.perf_counter() - t0
 
 
+def config5_leg(ctx, dev, steps, with_ids):
+    """1M atoms in one structure, 960 points, AtomLevel (BASELINE.json configs[4]): the default stepping (two batches in
+    flight), kernel times from the library's HIP events.  Timing only: parity at this size is the GPU tests' job."""
+    import numpy as np
+    import torch
+    import bench_workloads as bw
+    b = bw.synthetic_uniform(1_000_000, seed=5)
+    run = DeviceRun(ctx, b, 960, dev, with_ids, None)
+    run.enqueue(k=0)
+    for i in range(1, 4):
+        run.enqueue(k=i % 2)
+        ctx.wait()
+    ctx.wait()
+    ctx.enable_timing(True)
+    occl, grid = [], []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.enqueue(k=0)
+    for i in range(1, steps):
+        run.enqueue(k=i % 2)
+        ctx.wait()
+        t = ctx.timings()
+        occl.append(t["occlusion_ms"])
+    ctx.wait()
+    occl.append(ctx.timings()["occlusion_ms"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ctx.enable_timing(False)
+    for _ in range(3):  # grid build alone: one batch at a time
+        ctx.enable_timing(True)
+        run.step()
+        grid.append(ctx.timings()["grid_build_ms"])
+        ctx.enable_timing(False)
+    total = float(run.outs[0][0].sum().item())
+    del run
+    return {"workload": "synthetic 1M-atom structure, 960 points, probe 1.4, AtomLevel (BASELINE.json configs[4])",
+            "steps": steps, "ms_per_step": round(el / steps * 1e3, 4), "occlusion_ms": round(float(np.mean(occl)), 4),
+            "grid_build_ms": round(float(np.min(grid)), 4), "atoms_per_s": round(b.n_atoms * steps / el, 1),
+            "total_sasa": round(total, 1)}
+
+
+def files_leg(n_files):
+    """Directory mode (reference src/main.rs:342-480): n synthetic PDB files on /dev/shm -> per-residue values through
+    the C++ host API's process_files (sasa_host_cli, its own process: parse threads + GPU batches), three calls in one
+    process.  The files are written here (untimed)."""
+    import shutil
+    import tempfile
+    import numpy as np
+    import bench_workloads as bw
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_files as bf
+    cli = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="rsasa_bench_files_", dir=base)
+    try:
+        rng = np.random.default_rng(bw.PROTEOME_SEED)
+        sizes = np.clip(rng.lognormal(np.log(2000.0), 0.75, n_files), 150, 25000).astype(int)
+        doms = bf.load_domains()
+        paths, atoms = [], 0
+        for i, n_t in enumerate(sizes):
+            p = os.path.join(d, f"s{i:05d}.pdb")
+            atoms += bf.write_structure(p, int(n_t), rng, doms)
+            paths.append(p)
+        lst = os.path.join(d, "files.txt")
+        open(lst, "w").write("\n".join(paths) + "\n")
+        nbytes = sum(os.path.getsize(p) for p in paths)
+        p = subprocess.run([cli, "files", "residue", lst, "--threads", "0", "--batch", "0", "--workers", "0",
+                            "--devices", "1", "--calls", "3"], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            return {"error": p.stderr[-300:]}
+        r = json.loads(p.stdout)
+        calls = r["calls_s"]
+        return {"files": n_files, "atoms": atoms, "bytes_on_disk": nbytes,
+                "files_per_s": round(n_files / calls[0], 1),
+                "files_per_s_later_calls": round(n_files / min(calls[1:]), 1) if len(calls) > 1 else None,
+                "calls_s": [round(c, 4) for c in calls], "host_threads": os.cpu_count(),
+                "note": "files_per_s: the first process_files call of a fresh process (HIP start-up inside); later calls "
+                        "of the same process: files_per_s_later_calls; PDB text on /dev/shm, parse + selection + GPU + "
+                        "ResidueLevel results on the host"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -316,6 +446,9 @@ def main():
         return dry_run(args, dist, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # NUMA: before any pinned allocation and before the library starts its threads
+    all_cpus = os.sched_getaffinity(0)
+    numa = numa_bind(gpu_pci_address(torch, local_rank))
 
     import rustsasa_amd
     scaling = args.scaling if args.workload == "proteome" else "weak"
@@ -323,8 +456,9 @@ def main():
     batch, n_points, name = make_workload(args.workload, args.structures, args.n_points, rank, world,
                                           scaling, shard_of)
     # The host-to-host leg's pinned arrays and its first calls (which allocate the library's staging and sub-batch
-    # buffers) come first: allocated after the gigabytes of the device-resident run, the same code measures 6.2-6.7
-    # instead of 5.8 ms per batch (memory placement, not the library: tools/bench_h2h.py never saw it).
+    # buffers) come first (round 3 saw 6.2-6.7 instead of 5.8 ms per batch when they were allocated after the gigabytes
+    # of the device-resident run; with the process bound to the GPU's NUMA node - numa_bind above - placement no
+    # longer depends on the order, the order is kept for comparability).
     h2h_arrays = None
     if args.h2h_steps > 0:
         def pin(a):
@@ -378,13 +512,17 @@ def main():
         grid_ms.append(t["grid_build_ms"])
         agg_ms.append(t["aggregate_ms"])
 
+    step_done = []  # wall clock when each step's results were complete
+
     def timed_region():
         run.enqueue(k=0)
         for i in range(1, args.steps):
             run.enqueue(k=i % 2)
             ctx.wait()
+            step_done.append(time.perf_counter())
             collect()
         ctx.wait()
+        step_done.append(time.perf_counter())
         collect()
 
     elapsed = timed(dist, 1, timed_region)
@@ -446,6 +584,15 @@ def main():
                 "ms_per_step": round(w_el / args.weak_steps * 1e3, 4), "steps": args.weak_steps,
                 "structures_per_gpu": wb.n_structures}
         del wrun
+
+    # ---- secondary (rank 0, one GPU): BASELINE.json configs[4], 1M atoms in one structure x 960 points, timing only ----
+    config5 = None
+    if rank == 0 and world == 1 and args.workload == "proteome" and args.config5_steps > 0 and not shard_of:
+        config5 = config5_leg(ctx, dev, args.config5_steps, not args.no_ids)
+    # ---- secondary (rank 0, one GPU): directory mode, files on disk -> per-residue values (C++ process_files) ----
+    files_mode = None
+    if rank == 0 and world == 1 and args.workload == "proteome" and args.files > 0 and not shard_of:
+        files_mode = files_leg(args.files)
 
     if rank == 0:
         occl = float(np.mean(occl_ms))
@@ -512,6 +659,8 @@ def main():
                        "grid_cells_rank0": cells[0],
                        "atoms_per_s": round(total_atoms * args.steps / elapsed, 1),
                        "ids": not args.no_ids,
+                       "numa_node": numa["numa_node"], "cpus": numa["cpus"], "cpu_list": numa["cpu_list"],
+                       "gpu_pci": numa["gpu_pci"],
                        "parallelism": f"{world} rank(s), one per GPU, independent shards, no data-path "
                                       f"collective"},
             "roofline": roofline,
@@ -523,8 +672,18 @@ def main():
                                   "wall time here includes that wait: alone it takes one_at_a_time.grid_build_kernel_ms), "
                                   "occlusion kernels run one after the other"},
         }
+        if len(step_done) > 2:
+            d = np.diff(np.array(step_done)) * 1e3  # (the first step also carries the second one's enqueue: left out)
+            line["ms_per_step_min"] = round(float(d.min()), 4)
+            line["ms_per_step_median"] = round(float(np.median(d)), 4)
+            line["ms_per_step_max"] = round(float(d.max()), 4)
         if h2h:
+            line["value_host_to_host"] = h2h["value"]  # SURVEY 8d's definition (host SoA in, residue values out)
             line["host_to_host"] = h2h
+        if config5:
+            line["config5"] = config5
+        if files_mode:
+            line["files_mode"] = files_mode
         if two:
             line["one_at_a_time"] = two
         if shard_of:
@@ -532,6 +691,7 @@ def main():
         if weak:
             line["weak_scaling"] = weak
         if args.cpu_seconds > 0:  # (rank 0, on its own shard at N > 1)
+            os.sched_setaffinity(0, all_cpus)  # the CPU baseline gets every core (its threads are created in there)
             line["cpu_baseline"], cmp_idx, want = cpu_baseline(batch, n_points, args.cpu_seconds)
             line["parity"] = parity(batch, cmp_idx, want, got_atoms, got_res)
         print(json.dumps(line), flush=True)
@@ -548,6 +708,11 @@ def dry_run(args, dist, rank, world):
     dev = torch.device("cpu")
     batch, n_points, name = make_workload("proteome", args.structures or 64, args.n_points, rank, world,
                                           args.scaling)
+    # the NUMA binding of a real run, against a sysfs tree and PCI addresses the test provides
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    bdfs = [b for b in os.environ.get("RSASA_DRYRUN_GPU_PCI", "").split(",") if b]
+    numa = numa_bind(bdfs[local_rank] if local_rank < len(bdfs) else None, os.environ.get("RSASA_DRYRUN_SYSFS", "/sys"))
+    numa["affinity_after"] = sorted(os.sched_getaffinity(0))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pass
@@ -555,7 +720,7 @@ def dry_run(args, dist, rank, world):
     elapsed, total_structures, total_atoms = aggregate(dist, dev, elapsed, batch.n_structures, batch.n_atoms)
     shards = [None] * world
     mine = (rank, [int(i) for i in getattr(batch, "shard_indices", np.arange(batch.n_structures))],
-            batch.n_atoms, float(batch.x.sum(dtype=np.float64)))
+            batch.n_atoms, float(batch.x.sum(dtype=np.float64)), numa)
     if dist:
         dist.all_gather_object(shards, mine)
     else:
@@ -571,6 +736,7 @@ def dry_run(args, dist, rank, world):
                           "config": {"workload": name, "structures_total": int(total_structures),
                                      "atoms_total": int(total_atoms)},
                           "shards_disjoint_and_complete": complete,
+                          "numa": [s[4] for s in shards],
                           "shard_atoms": [s[2] for s in shards],
                           "shard_structures": [len(s[1]) for s in shards]}), flush=True)
     if dist:

@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define RSASA_ABI_VERSION 1
+/* 2: rsasa_batch_wait returns the OLDEST of up to two batches in flight (version 1 had one batch in flight, so
+ * "the" batch); rsasa_batch_wait_all, rsasa_context_get_simd_width, rsasa_context_bind_thread added. */
+#define RSASA_ABI_VERSION 2
 
 typedef enum rsasa_status {
     RSASA_OK = 0,
@@ -56,8 +58,9 @@ const char *rsasa_status_string(int status);
 /* Number of HIP devices visible to this process (0 is a valid answer). */
 int rsasa_device_count(int *out_count);
 
-/* One context = one GPU + one HIP stream + a growable HBM workspace and a
- * cached sphere lattice.  Calls on one context are serialised by an internal
+/* One context = one GPU + two launch streams with a growable HBM workspace
+ * each (two batches in flight, see rsasa_batch_enqueue), copy streams of the
+ * host-pointer entry points, and the cached sphere lattices.  Calls on one context are serialised by an internal
  * mutex; use one context per host thread (or per rayon worker) for
  * concurrency.  Replaces the reference's global rayon pool
  * (src/utils.rs:63-81) as the unit of parallel resources. */
@@ -72,6 +75,17 @@ int rsasa_context_get_device(const rsasa_context_t *ctx, int *out_device);
  * the last (n_points mod W) sphere points use the reference's scalar
  * remainder rule -- unfused dot product and `<=` (src/lib.rs:163-218). */
 int rsasa_context_set_simd_width(rsasa_context_t *ctx, int simd_width);
+int rsasa_context_get_simd_width(rsasa_context_t *ctx, int *out_simd_width);
+
+/* Multi-socket hosts: binds the CALLING thread to the CPUs of the NUMA node the
+ * context's GPU hangs off (sysfs numa_node / local_cpulist of its PCI address;
+ * the context's own worker threads are bound the same way when they start).
+ * A host program with one worker thread per GPU - the reference runs one rayon
+ * worker per structure, src/main.rs:375 - calls this once at the top of each
+ * worker, before it allocates the buffers it hands to the context.
+ * *out_numa_node (nullable) receives the node, or -1 when the machine has one
+ * node, hides its topology, or RSASA_NUMA=0 is set; then nothing is bound. */
+int rsasa_context_bind_thread(rsasa_context_t *ctx, int *out_numa_node);
 
 /* ---- the hot path, one structure per call ------------------------------ */
 
@@ -143,6 +157,8 @@ typedef struct rsasa_device_batch {
 int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
                         float probe_radius, size_t n_points, void *hip_stream);
 int rsasa_batch_wait(rsasa_context_t *ctx);
+/* Waits for EVERY batch in flight (oldest first) and returns the first error. */
+int rsasa_batch_wait_all(rsasa_context_t *ctx);
 
 /* MD-trajectory mode (the reference ecosystem's second workload: per-frame SASA of one
  * topology, README.md:98-149 / paper.md:45): n_frames frames of the same n_atoms atoms.

@@ -187,6 +187,7 @@ struct FilesTimings {
     double compute_seconds = 0;  // packing, H2D, GPU hot path, D2H, result mapping (GPU workers, summed; overlaps parsing)
     double total_seconds = 0;
     std::size_t n_files = 0, n_atoms = 0;
+    std::vector<int> worker_simd_widths;  // the pulp lane count every GPU worker's context ran with (the caller's, on each)
 };
 
 // What ChainLevel hands to the hot path for one structure: the kept atoms (build_atoms_and_mapping,

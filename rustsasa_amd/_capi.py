@@ -68,6 +68,8 @@ SYMBOLS = {
     "rsasa_context_last_error": (C.c_char_p, [_vp]),
     "rsasa_context_get_device": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "rsasa_context_set_simd_width": (C.c_int, [_vp, C.c_int]),
+    "rsasa_context_get_simd_width": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "rsasa_context_bind_thread": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "rsasa_calculate_sasa_internal": (C.c_int, [_vp, _vp, C.c_size_t, C.c_float, C.c_size_t,
                                                 C.c_ssize_t, _vp]),
     "rsasa_calculate_sasa_soa": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, C.c_float,
@@ -79,6 +81,7 @@ SYMBOLS = {
     "rsasa_segment_sums": (C.c_int, [_vp, _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "rsasa_batch_enqueue": (C.c_int, [_vp, C.POINTER(DeviceBatch), C.c_float, C.c_size_t, _vp]),
     "rsasa_batch_wait": (C.c_int, [_vp]),
+    "rsasa_batch_wait_all": (C.c_int, [_vp]),
     "rsasa_context_enable_timing": (C.c_int, [_vp, C.c_int]),
     "rsasa_context_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
     "rsasa_sphere_points": (C.c_int, [C.c_size_t, _vp, _vp, _vp]),

@@ -22,6 +22,9 @@
 #include <utility>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+
 #include "device_types.h"
 
 namespace rsasa {
@@ -93,6 +96,72 @@ struct DeviceBuffer {
     size_t cap = 0;
 };
 
+// CPUs of the NUMA node a GPU hangs off, from sysfs (numa_node / local_cpulist of its PCI address).  `valid` only on
+// machines that have more than one node and say so; RSASA_NUMA=0 switches the whole thing off.  Used to keep the
+// context's own threads (and, through rsasa_context_bind_thread, the caller's per-GPU worker threads) next to the
+// link their pinned buffers cross - with 8 GPUs on two sockets half of them would otherwise work across the socket
+// interconnect (reference: one rayon pool per process, src/main.rs:375; here one context per GPU).
+struct NodeCpus {
+    bool valid = false;
+    int node = -1;
+    cpu_set_t set;
+};
+
+static NodeCpus device_node_cpus(int device)
+{
+    NodeCpus nc;
+    CPU_ZERO(&nc.set);
+    if (const char *v = std::getenv("RSASA_NUMA"))
+        if (std::atoi(v) == 0) return nc;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return nc;
+    }
+    for (char *c = bdf; *c; c++) *c = (char)std::tolower((unsigned char)*c);
+    const std::string base = std::string("/sys/bus/pci/devices/") + bdf;
+    FILE *f = std::fopen((base + "/numa_node").c_str(), "r");
+    if (!f) return nc;
+    int node = -1;
+    const int got = std::fscanf(f, "%d", &node);
+    std::fclose(f);
+    if (got != 1 || node < 0) return nc;
+    f = std::fopen((base + "/local_cpulist").c_str(), "r");
+    if (!f) return nc;
+    char buf[4096] = {0};
+    const bool ok = std::fgets(buf, sizeof(buf), f) != nullptr;
+    std::fclose(f);
+    if (!ok) return nc;
+    int n_set = 0;
+    for (char *q = buf; *q;) {  // "0-31,64-95"
+        char *end = nullptr;
+        const long lo = std::strtol(q, &end, 10);
+        if (end == q) break;
+        long hi = lo;
+        q = end;
+        if (*q == '-') {
+            hi = std::strtol(q + 1, &end, 10);
+            q = end;
+        }
+        for (long c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET((int)c, &nc.set); n_set++; }
+        while (*q == ',' || *q == ' ' || *q == '\n') q++;
+    }
+    nc.node = node;
+    nc.valid = n_set > 0;
+    return nc;
+}
+
+// Binds a thread to `nc` (intersected with what the thread may run on); false when there is nothing to do.
+static bool bind_thread_to(pthread_t th, const NodeCpus &nc)
+{
+    if (!nc.valid) return false;
+    cpu_set_t cur, want;
+    if (pthread_getaffinity_np(th, sizeof(cur), &cur) != 0) return false;
+    CPU_AND(&want, &cur, &nc.set);
+    if (CPU_COUNT(&want) == 0) return false;
+    return pthread_setaffinity_np(th, sizeof(want), &want) == 0;
+}
+
 struct LatticeEntry {
     float *d = nullptr;  // x | y | z, each `padded` floats, | (x, y, z, 0) records | patch table (16 bytes per patch)
     uint32_t padded = 0;
@@ -145,9 +214,12 @@ struct RadiusCodec {
 // worked off in the order they were submitted, every worker taking blocks of the current job.
 class FoldPool {
 public:
-    explicit FoldPool(unsigned n_threads)
+    FoldPool(unsigned n_threads, const NodeCpus &node)
     {
-        for (unsigned t = 0; t < n_threads; t++) workers.emplace_back([this] { run(); });
+        for (unsigned t = 0; t < n_threads; t++) {
+            workers.emplace_back([this] { run(); });
+            (void)bind_thread_to(workers.back().native_handle(), node);  // next to the GPU's link (see NodeCpus)
+        }
     }
     ~FoldPool()
     {
@@ -238,6 +310,7 @@ using namespace rsasa;
 
 struct rsasa_context {
     int device = 0;
+    NodeCpus node;                                // CPUs of the GPU's NUMA node (valid on multi-node hosts only)
     hipStream_t stream = nullptr;
     std::recursive_mutex mu;
     std::string last_error;
@@ -369,7 +442,13 @@ int reserve(rsasa_context *ctx, DeviceBuffer &b, size_t bytes)
 {
     if (bytes <= b.cap) return RSASA_OK;
     if (b.p) {
+        // the buffer may be read by work on any of the context's streams (two launch streams, a caller's stream of a
+        // batch in flight, the copy streams of the pipelined host path): drain them all, not only the first
         RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->stream2) RS_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+        if (ctx->side_stream) RS_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
+        for (const Pending &pd : ctx->pending)
+            if (pd.active && pd.stream && pd.stream != ctx->stream && pd.stream != ctx->stream2) RS_HIP(ctx, hipStreamSynchronize(pd.stream));
         RS_HIP(ctx, hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -775,6 +854,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     rsasa_context *ctx = new (std::nothrow) rsasa_context();
     if (!ctx) return RSASA_ERR_OUT_OF_MEMORY;
     ctx->device = device;
+    ctx->node = device_node_cpus(device);
     DeviceGuard guard(device);
     hipError_t e = guard.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -893,11 +973,35 @@ int rsasa_context_set_simd_width(rsasa_context_t *ctx, int w)
     return RSASA_OK;
 }
 
+int rsasa_context_get_simd_width(rsasa_context_t *ctx, int *out_simd_width)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (!out_simd_width) return RSASA_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    *out_simd_width = ctx->simd_width;
+    return RSASA_OK;
+}
+
+int rsasa_context_bind_thread(rsasa_context_t *ctx, int *out_numa_node)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (out_numa_node) *out_numa_node = ctx->node.valid ? ctx->node.node : -1;
+    (void)bind_thread_to(pthread_self(), ctx->node);
+    return RSASA_OK;
+}
+
 int rsasa_context_enable_timing(rsasa_context_t *ctx, int enable)
 {
     int rc = resolve_ctx(ctx);
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    // a batch enqueued under the other setting has (or lacks) its events: finish what is in flight first
+    if (ctx->n_pending && (ctx->timing != (enable != 0))) {
+        RS_DEVICE(ctx);
+        if ((rc = wait_pending(ctx))) return rc;
+    }
     ctx->timing = enable != 0;
     ctx->timings_valid = false;
     return RSASA_OK;
@@ -973,6 +1077,15 @@ int rsasa_batch_wait(rsasa_context_t *ctx)
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
     return wait_oldest(ctx);
+}
+
+int rsasa_batch_wait_all(rsasa_context_t *ctx)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    RS_DEVICE(ctx);
+    return wait_pending(ctx);
 }
 
 namespace {
@@ -1329,7 +1442,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     if ((fold_ids || code_radii) && !ctx->fold_pool) {
         unsigned nt = std::thread::hardware_concurrency() / 4;
         if (const char *v = std::getenv("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
-        ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)));
+        ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)), ctx->node);
         if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
     }
     std::vector<unsigned long long> fold_job(cut.size(), 0);

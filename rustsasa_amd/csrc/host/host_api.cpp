@@ -11,6 +11,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -1190,15 +1191,53 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // for the duration of the call (calls on one context are serialised)
     std::vector<rsasa_context_t *> contexts = o.contexts;
     if (contexts.empty()) contexts.push_back(o.context);
+    // The companion context is kept for the life of the process, one per device (a context is a GPU workspace and a few
+    // threads: creating one per call cost more than the call's second chunk); a call that finds it taken creates its
+    // own.  It runs with the caller's context's settings: the pulp lane count decides which points take the remainder
+    // rule, and chunks go to whichever worker is free.
+    struct Companion {
+        rsasa_context_t *ctx = nullptr;
+        bool busy = false;
+    };
+    static std::mutex companions_mu;
+    static std::map<int, Companion> companions;
     struct Borrowed {
         rsasa_context_t *ctx = nullptr;
-        ~Borrowed() { if (ctx) rsasa_context_destroy(ctx); }
+        int device = -1;
+        bool cached = false;
+        ~Borrowed()
+        {
+            if (cached) {
+                std::lock_guard<std::mutex> lk(companions_mu);
+                companions[device].busy = false;
+            } else if (ctx) {
+                rsasa_context_destroy(ctx);
+            }
+        }
     } second;
     if (contexts.size() == 1 && paths.size() > files_per_batch) {
         int device = 0;
-        if (contexts[0] && rsasa_context_get_device(contexts[0], &device) != RSASA_OK) device = 0;
-        if (rsasa_context_create(device, &second.ctx) == RSASA_OK) contexts.push_back(second.ctx);
-        else contexts.push_back(contexts[0]);  // (no second context: two workers share the one, as before)
+        if (rsasa_context_get_device(contexts[0], &device) != RSASA_OK) device = 0;
+        second.device = device;
+        {
+            std::lock_guard<std::mutex> lk(companions_mu);
+            Companion &c = companions[device];
+            if (!c.busy) {
+                if (!c.ctx && rsasa_context_create(device, &c.ctx) != RSASA_OK) c.ctx = nullptr;
+                if (c.ctx) {
+                    c.busy = true;
+                    second.ctx = c.ctx;
+                    second.cached = true;
+                }
+            }
+        }
+        if (!second.ctx && rsasa_context_create(device, &second.ctx) != RSASA_OK) second.ctx = nullptr;
+        int simd_width = 8;
+        if (second.ctx && rsasa_context_get_simd_width(contexts[0], &simd_width) == RSASA_OK &&
+            rsasa_context_set_simd_width(second.ctx, simd_width) == RSASA_OK)
+            contexts.push_back(second.ctx);
+        else
+            contexts.push_back(contexts[0]);  // (no second context: two workers share the one)
     }
 
     struct Chunk {
@@ -1246,6 +1285,13 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     auto worker = [&](rsasa_context_t *ctx) {
         OptionValues mine = o;
         mine.context = ctx;
+        (void)rsasa_context_bind_thread(ctx, nullptr);  // multi-socket hosts: this worker next to its GPU's link
+        {
+            int w = 0;
+            (void)rsasa_context_get_simd_width(ctx, &w);
+            std::lock_guard<std::mutex> lk(mu_t);
+            t.worker_simd_widths.push_back(w);
+        }
         // the first touch of a context initialises the HIP runtime (a quarter of a second): do it
         // here, while the producer parses the first chunk
         (void)rsasa_segment_sums(ctx, nullptr, 0, nullptr, 0, nullptr);

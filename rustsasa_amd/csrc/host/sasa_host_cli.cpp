@@ -66,12 +66,14 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     bool full = false;
     int workers = 0, devices = 1;  // --workers K: K GPU worker contexts, on devices k % --devices
     int calls = 1;                 // --calls N: process_files N times in this process (the last call's results are printed)
+    int simd_width = 0;            // --simd-width W: the pulp lane count of the context(s) the call is given (0: default)
     for (int i = 4; i < argc; i++) {
         if (!std::strcmp(argv[i], "--threads") && i + 1 < argc) threads = (unsigned)std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--batch") && i + 1 < argc) batch = (size_t)std::atol(argv[i + 1]);
         if (!std::strcmp(argv[i], "--workers") && i + 1 < argc) workers = std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--devices") && i + 1 < argc) devices = std::max(1, std::atoi(argv[i + 1]));
         if (!std::strcmp(argv[i], "--calls") && i + 1 < argc) calls = std::max(1, std::atoi(argv[i + 1]));
+        if (!std::strcmp(argv[i], "--simd-width") && i + 1 < argc) simd_width = std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--full")) full = true;
     }
     std::vector<rsasa_context_t *> ctxs;
@@ -83,7 +85,9 @@ static int run_files(int argc, char **argv, PrintOne print_one)
             return 70;
         }
         ctxs.push_back(c);
+        if (simd_width && rsasa_context_set_simd_width(c, simd_width) != RSASA_OK) return 71;
     }
+    if (simd_width && ctxs.empty() && rsasa_context_set_simd_width(nullptr, simd_width) != RSASA_OK) return 71;  // (the default context)
     FilesTimings t;
     auto opts = make<L>(argc - 1, argv + 1);
     if (!ctxs.empty()) opts.with_contexts(ctxs);
@@ -96,8 +100,10 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     for (rsasa_context_t *c : ctxs) rsasa_context_destroy(c);
     size_t n_ok = 0;
     for (const auto &r : res) n_ok += r.ok();
-    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"calls_s\":[%s],\"results\":[",
-                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds, call_s.c_str());
+    std::string widths;
+    for (int w : t.worker_simd_widths) widths += (widths.empty() ? "" : ",") + std::to_string(w);
+    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"calls_s\":[%s],\"worker_simd_widths\":[%s],\"results\":[",
+                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds, call_s.c_str(), widths.c_str());
     for (size_t i = 0; i < res.size(); i++) {
         std::printf("%s", i ? "," : "");
         if (!res[i].ok()) {

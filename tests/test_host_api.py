@@ -286,6 +286,26 @@ def test_process_files_matches_oracle(tmp_path, batch, workers):
                                     single["non_polar_total"]], np.float32))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [0, 1])
+def test_process_files_companion_context_runs_with_the_callers_settings(tmp_path, workers):
+    """With one context and more files than a chunk holds, process_files puts a second (cached) context on the same
+    GPU beside it; chunks go to whichever worker is free, so the companion must carry the caller's pulp lane
+    count (it decides which points take the remainder rule) - results would otherwise depend on the run.  Twice in
+    one process: the second call finds the cached companion."""
+    paths, lst = _make_file_set(tmp_path, 12)
+    p = subprocess.run([CLI, "files", "residue", lst, "--threads", "4", "--batch", "4", "--full", "--simd-width", "4",
+                        "--workers", str(workers), "--calls", "2"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:500]
+    got = json.loads(p.stdout)
+    assert got["worker_simd_widths"] == [4, 4], got["worker_simd_widths"]
+    assert got["n_ok"] == len(paths) - 2
+    # (on these files the oracle's values are the same for every lane count: the widths above are the check)
+    i_cif = paths.index(sio.data_path("example.cif"))
+    _, res, _ = expected("example.cif")
+    assert np.array_equal(np.array(got["results"][i_cif], np.float32), res)
+
+
 # ---- writers (reference src/utils/io.rs) ---------------------------------------------
 
 @pytest.mark.parametrize("name", ["1jcd.pdb", "151L_H3.pdb", "2drt.pdb"])
