@@ -131,6 +131,21 @@ def gpu_pci_address(torch, index):
         return None
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time this process's cgroup may use per period (cgroup v2 cpu.max, v1 cfs quota), or None."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def physical_cores():
     """Distinct (socket, core) pairs of /proc/cpuinfo (None when it does not say)."""
     seen, phys = set(), None
@@ -155,7 +170,12 @@ def cpu_baseline(batch, n_points, target_seconds):
     import numpy as np
     import bench_workloads as bw
     from oracle import pyoracle as po
-    threads = min(po.max_threads(), os.cpu_count() or 1)
+    # every CPU this process may really use: the hardware threads it is allowed on, capped by its cgroup's CPU quota
+    # (a container with cpu.max = 16 CPUs on a 256-thread host runs 16 threads' worth of work however many it starts:
+    # 128 threads there are throttled, not faster)
+    hw = min(po.max_threads(), len(os.sched_getaffinity(0)), os.cpu_count() or 1)
+    quota = cgroup_cpu_quota()
+    threads = max(1, min(hw, int(quota + 0.5))) if quota else hw
 
     def run(b, n_threads):
         t0 = time.perf_counter()
@@ -188,7 +208,8 @@ def cpu_baseline(batch, n_points, target_seconds):
            "sample": f"every k-th structure of the list, k = {every1}: {b1.n_structures} structures ({b1.n_atoms} atoms), "
                      f"best of 3 runs, {t1:.2f} s wall"}
     line = {"value": round(b.n_structures / t, 3), "unit": "structures/s", "cores": threads, "kind": "port",
-            "threads_used": threads, "physical_cores": physical_cores(),
+            "threads_used": threads, "hardware_threads": hw, "physical_cores": physical_cores(),
+            "cgroup_cpu_quota": quota,
             "atoms_per_s": round(b.n_atoms / t, 1),
             "speedup_over_one_thread": round((b.n_atoms / t) / (b1.n_atoms / t1), 2),
             "sample": (f"all {b.n_structures}" if every == 1 else f"every k-th structure of the list, k = {every}: {b.n_structures} of {batch.n_structures}")
@@ -408,7 +429,7 @@ def files_leg(n_files):
             return {"error": p.stderr[-300:]}
         r = json.loads(p.stdout)
         calls = r["calls_s"]
-        return {"files": n_files, "atoms": atoms, "bytes_on_disk": nbytes,
+        return {"files": n_files, "atoms": int(atoms), "bytes_on_disk": int(nbytes),
                 "files_per_s": round(n_files / calls[0], 1),
                 "files_per_s_later_calls": round(n_files / min(calls[1:]), 1) if len(calls) > 1 else None,
                 "calls_s": [round(c, 4) for c in calls], "host_threads": os.cpu_count(),
@@ -694,7 +715,7 @@ def main():
             os.sched_setaffinity(0, all_cpus)  # the CPU baseline gets every core (its threads are created in there)
             line["cpu_baseline"], cmp_idx, want = cpu_baseline(batch, n_points, args.cpu_seconds)
             line["parity"] = parity(batch, cmp_idx, want, got_atoms, got_res)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)
 
     ctx.close()
     if dist:
