@@ -38,7 +38,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PEAK_INSTS = 1024 * 2.4e9 / 2.0   # wave64 VALU instructions/s: 1024 SIMD-32s, 2 cycles each, 2.4 GHz
 VALU_PEAK_TFLOPS = 157.3        # f32 vector peak (MI355X_MICROARCH.md)
 PROBE = 1.4
 N_POINTS = 100
@@ -615,6 +614,10 @@ def main():
     if rank == 0 and world == 1 and args.workload == "proteome" and args.files > 0 and not shard_of:
         files_mode = files_leg(args.files)
 
+    if config5:
+        pmcu, _ = load_pmc("pmc_uniform1m.json")
+        if pmcu.get("alu_busy"):
+            config5["alu_busy"] = pmcu["alu_busy"]  # (counters of a profiled single launch of this build: profiles/)
     if rank == 0:
         occl = float(np.mean(occl_ms))
         pmc, pmc_state = load_pmc("pmc_occlusion.json")
@@ -627,19 +630,16 @@ def main():
                                    "the north_star figure; the kernel itself is bound by the vector + matrix ALU "
                                    "(alu_busy), its HBM-side traffic is `traffic`",
                         "traffic": pmc.get("hbm_bytes_per_launch") if full_batch else None,
-                        "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of this workload, "
+                        "traffic_source": PMC_FILE + " (rocprofv3 --pmc passes of one launch of this workload, "
                                                      "see profiles/README.md): " + (pmc_state if full_batch else
                                                                                     "not this workload"),
                         "algorithmic_bytes_per_launch": algorithmic_bytes,
                         "kernel_ms": round(occl, 4)}
-            vi = pmc.get("valu_insts_per_launch")
-            if vi and full_batch:
-                rate = vi / (occl * 1e-3)
-                roofline["valu_issue"] = {"insts_per_launch": vi, "achieved_insts_per_s": round(rate, 1),
-                                          "peak_insts_per_s": VALU_PEAK_INSTS,
-                                          "frac": round(rate / VALU_PEAK_INSTS, 4), "source": PMC_FILE}
             if pmc.get("alu_busy") and full_batch:
+                # counters of ONE profiled launch of this build (rocprofv3 --pmc, --steps 1: no neighbouring batch), with
+                # that launch's own cycle count: a modelled occupancy, both variants printed (profiles/README.md)
                 roofline["alu_busy"] = pmc["alu_busy"]
+                roofline["insts_per_launch"] = {"vector": pmc.get("valu_insts_per_launch"), "scalar": pmc.get("salu_insts_per_launch")}
         else:
             # config 5 is bound by the vector ALUs: no HBM fraction is claimed.  Utilisation =
             # vector instructions the occlusion launch executed (rocprofv3 SQ_INSTS_VALU, profiles/) x 64

@@ -338,6 +338,13 @@ struct rsasa_context {
     } ws[2];
     static constexpr int kInFlight = 2;
     hipStream_t stream2 = nullptr;                // launch stream of workspace 1 (created by the first overlapped enqueue)
+    // Experiment (RSASA_GRID_CUS=N): N compute units are set aside for the grid builds - a stream masked to
+    // them - and the two launch streams are masked to the others, so batch k + 1's grid build runs BESIDE batch k's
+    // occlusion kernel instead of waiting for its workgroups to retire.
+    uint32_t grid_cus = 0, cu_mask_words = 0;
+    uint32_t cu_reserved[16] = {}, cu_rest[16] = {};
+    hipStream_t grid_stream = nullptr;
+    hipEvent_t ev_grid[2] = {nullptr, nullptr};
     DeviceBuffer &segments = ws[0].segments, &acc = ws[0].acc, &grids = ws[0].grids, &grid_sums = ws[0].grid_sums,
                  &sid_sorted = ws[0].sid_sorted, &deferred_list = ws[0].deferred_list, &cell_of = ws[0].cell_of,
                  &rank_of = ws[0].rank_of, &cells = ws[0].cells, &windows = ws[0].windows, &scan_sums = ws[0].scan_sums,
@@ -680,8 +687,11 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     // Launch stream: grids -> LDS binning -> occlusion of the LDS-binned structures -> (join) ->
     // occlusion of the tail -> sums.  Side stream (forked after the LDS binning): the tail's
     // batch-wide binning, which is bandwidth bound and runs next to the compute-bound occlusion kernel.
-    if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[0], st));
-    launch_grid_prepare(v, st);
+    // (RSASA_GRID_CUS experiment: the grid build on the stream of the reserved CUs, the rest behind an event)
+    const bool masked = ctx->grid_stream && (pd.stream == ctx->stream || pd.stream == ctx->stream2) && !(ctx->overlap_tail && has_tail);
+    hipStream_t gst = masked ? ctx->grid_stream : st;
+    if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[0], gst));
+    launch_grid_prepare(v, gst);
     // Two batches in flight: this one's grid build is enqueued beside the other one's occlusion kernel (it gets the CUs
     // when that kernel's workgroups retire: the kernel leaves a CU no room), its occlusion kernel behind it.
     rsasa_context::Workspace &other = ctx->ws[pd.ws ^ 1];
@@ -703,9 +713,13 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
         RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
         launch_occlusion(v, lat, ctx->tuning, kOccRest, st);
     } else {
-        launch_sort_lds(v, st);
-        if (has_tail) launch_sort_tail(v, st);
-        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[1], st));
+        launch_sort_lds(v, gst);
+        if (has_tail) launch_sort_tail(v, gst);
+        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[1], gst));
+        if (masked) {
+            RS_HIP(ctx, hipEventRecord(ctx->ev_grid[pd.ws], gst));
+            RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_grid[pd.ws], 0));
+        }
         if (chain) RS_HIP(ctx, hipStreamWaitEvent(st, other.ev_occ, 0));
         if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[2], st));
         launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
@@ -857,7 +871,32 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     ctx->node = device_node_cpus(device);
     DeviceGuard guard(device);
     hipError_t e = guard.err;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (const char *v = std::getenv("RSASA_GRID_CUS")) {
+        int n_cu = 0;
+        if (e == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0 && n_cu <= 512) {
+            const int want = std::atoi(v);
+            int stride = 1;  // RSASA_GRID_CU_STRIDE: reserved CUs are mask bits 0, stride, 2 stride, ...
+            if (const char *sv = std::getenv("RSASA_GRID_CU_STRIDE")) stride = std::max(1, std::atoi(sv));
+            if (want > 0 && want * stride <= n_cu && want < n_cu) {
+                ctx->grid_cus = (uint32_t)want;
+                ctx->cu_mask_words = (uint32_t)(n_cu + 31) / 32;
+                for (int c = 0; c < n_cu; c++) ctx->cu_rest[c / 32] |= 1u << (c % 32);
+                for (int k = 0; k < want; k++) {
+                    const int c = k * stride;
+                    ctx->cu_reserved[c / 32] |= 1u << (c % 32);
+                    ctx->cu_rest[c / 32] &= ~(1u << (c % 32));
+                }
+            }
+        }
+    }
+    if (e == hipSuccess && ctx->grid_cus) {
+        e = hipExtStreamCreateWithCUMask(&ctx->stream, ctx->cu_mask_words, ctx->cu_rest);
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->stream2, ctx->cu_mask_words, ctx->cu_rest);
+        if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->grid_stream, ctx->cu_mask_words, ctx->cu_reserved);
+        for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid[w], hipEventDisableTiming);
+    } else if (e == hipSuccess) {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    }
     for (int w = 0; w < rsasa_context::kInFlight; w++) {
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ws[w].ev[i]);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ws[w].ev_occ, hipEventDisableTiming);
@@ -926,6 +965,9 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
             release(*b);
     }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->grid_stream) (void)hipStreamDestroy(ctx->grid_stream);
+    for (hipEvent_t ev : ctx->ev_grid)
+        if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < rsasa_context::kSlots; i++)
         if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
     for (int i = 0; i < rsasa_context::kSlots; i++) {

@@ -52,22 +52,39 @@ out = {
     "salu_insts_per_launch": val("SQ_INSTS_SALU"),
     "kernel_source_sha16": bench_py.kernel_source_hash(),
 }
-try:
-    # vector + matrix ALU occupancy: plain vector instructions at the 2.7 cycles each costs a SIMD at full occupancy
-    # (tools/microbench_issue.hip), matrix instructions at the cycles SQ_VALU_MFMA_BUSY_CYCLES counts for them, over the
-    # kernel's cycles on the 1024 SIMDs (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
-    mfma, busy, coexec, gui = val("SQ_INSTS_MFMA"), val("SQ_VALU_MFMA_BUSY_CYCLES"), val("SQ_VALU_MFMA_COEXEC_CYCLES"), val("GRBM_GUI_ACTIVE")
-    cyc = gui / 8.0
-    out["alu_busy"] = {
+PRICE = 1.3  # real shader cycles a SIMD spends per vector instruction at this kernel's occupancy: MODELLED, from
+             # tools/microbench_clock.hip (dependent v_fma streams on 8 waves per SIMD: 1.30) and from the kernel itself
+             # (20 / 40 extra v_mov per atom: +1.15 / +1.3 cycles per atom and SIMD each; 20 s_mov: +1.4): DESIGN 6a
+
+
+def alu_busy(v, cyc):
+    """Vector + matrix pipe occupancy of one dispatch.  Two variants of the same model: the matrix instructions at the
+    cycles SQ_VALU_MFMA_BUSY_CYCLES counts, the other vector instructions at PRICE cycles each, over the kernel's
+    cycles on the 1024 SIMDs - with and without the cycles in which both kinds were in flight at once
+    (SQ_VALU_MFMA_COEXEC_CYCLES).  Neither is a counter; the instruction counts and the busy cycles are."""
+    mfma, busy, coexec = v("SQ_INSTS_MFMA"), v("SQ_VALU_MFMA_BUSY_CYCLES"), v("SQ_VALU_MFMA_COEXEC_CYCLES")
+    valu = v("SQ_INSTS_VALU")
+    other = {k: v(k) for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD")}
+    all_insts = valu + sum(other.values())
+    return {
+        "modelled": True,
+        "price_cycles_per_vector_inst": PRICE,
+        "price_source": "tools/microbench_clock.hip (real shader cycles, 8 waves per SIMD) and the in-kernel pad experiment (DESIGN 6a)",
         "mfma_insts_per_launch": mfma, "mfma_busy_cycles_per_launch": busy, "mfma_valu_coexec_cycles_per_launch": coexec,
-        "kernel_cycles": round(cyc), "valu_cycles_per_simd": round((out["valu_insts_per_launch"] - mfma) * 2.7 / 1024),
-        "mfma_cycles_per_simd": round(busy / 1024),
-        "frac": round(((out["valu_insts_per_launch"] - mfma) * 2.7 + busy) / 1024 / cyc, 3),
-        "definition": "((vector instructions - matrix instructions) x 2.7 cycles + SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs / "
-                      "(GRBM_GUI_ACTIVE / 8): share of the kernel's cycles in which a SIMD's vector / matrix pipe is taken; "
-                      "SQ_VALU_MFMA_COEXEC_CYCLES (cycles with both kinds in flight) is reported, not subtracted: "
-                      "tools/microbench_mfma2.hip shows the two adding up on one SIMD",
+        "kernel_cycles": round(cyc),
+        "frac_sum": round(((valu - mfma) * PRICE + busy) / 1024 / cyc, 3),
+        "frac_minus_coexec": round(((valu - mfma) * PRICE + busy - coexec) / 1024 / cyc, 3),
+        "insts_all_classes_per_launch": all_insts,
+        "issue_frac": round((all_insts * PRICE + busy) / 1024 / cyc, 3),
+        "definition": "frac_sum = ((vector - matrix instructions) x price + SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); "
+                      "frac_minus_coexec subtracts SQ_VALU_MFMA_COEXEC_CYCLES; issue_frac prices EVERY instruction (vector, scalar, "
+                      "branch, LDS, vector memory) at the same cycles - the pad experiment finds a scalar instruction no cheaper "
+                      "than a vector one - plus the matrix pipe's busy cycles",
     }
+
+
+try:
+    out["alu_busy"] = alu_busy(val, val("GRBM_GUI_ACTIVE") / 8.0)
 except Exception as e:  # (older pmc.txt without the matrix-pipe pass)
     print("no alu_busy:", e)
 json.dump(out, open(os.path.join(dst, "pmc_occlusion.json"), "w"), indent=2)
@@ -84,5 +101,9 @@ if os.path.exists(pu):
             "valu_insts_per_launch": vu("SQ_INSTS_VALU"), "mfma_insts_per_launch": vu("SQ_INSTS_MFMA"),
             "salu_insts_per_launch": vu("SQ_INSTS_SALU"), "lds_insts_per_launch": vu("SQ_INSTS_LDS"),
             "kernel_source_sha16": bench_py.kernel_source_hash()}
+    try:
+        outu["alu_busy"] = alu_busy(vu, vu("GRBM_GUI_ACTIVE") / 8.0)
+    except Exception as e:
+        print("no alu_busy for the many-point dispatch:", e)
     json.dump(outu, open(os.path.join(dst, "pmc_uniform1m.json"), "w"), indent=2)
     print(json.dumps(outu, indent=1))
