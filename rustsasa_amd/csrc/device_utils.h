@@ -100,6 +100,23 @@ __device__ __forceinline__ uint32_t load_cell_start(const uint32_t *cells, uint3
     return rel16 ? (uint32_t)reinterpret_cast<const uint16_t *>(cells)[idx] : cells[idx];
 }
 
+// Two entries at once, both loads in flight together (one branch on the entry width instead of one per load,
+// which also serialised them).
+__device__ __forceinline__ void load_cell_start2(const uint32_t *cells, uint32_t idx0, uint32_t idx1, bool rel16,
+                                                 uint32_t &v0, uint32_t &v1)
+{
+    if (rel16) {
+        const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cells);
+        const uint16_t a = c16[idx0], b = c16[idx1];
+        v0 = a;
+        v1 = b;
+    } else {
+        const uint32_t a = cells[idx0], b = cells[idx1];
+        v0 = a;
+        v1 = b;
+    }
+}
+
 // 64-bit atom id -> 32 bits.  Only used as a filter: ids whose folds differ are different; equal
 // folds are decided on the full ids (the general kernel).
 __device__ __forceinline__ uint32_t fold_id(uint64_t id) { return (uint32_t)id ^ ((uint32_t)(id >> 32) * 0x9E3779B1u); }
