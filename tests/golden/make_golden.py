@@ -27,6 +27,8 @@ DATA_FILES = [
 # whole tests/data/freesasa_pdbs directory, 46 MB; these are its six smallest alt-loc files), each
 # with its FreeSASA chain totals (tests/data/freesasa_reference/<id>.json).
 ALTLOC_IDS = ["2gpi", "3w7y", "3uc7", "3kyz", "4oxx", "3zsj"]
+# A small file WITH hydrogens from the same set (the include_hydrogens option, tests/test_host_api.py).
+HYDROGEN_IDS = ["4c1a"]
 
 
 def main():
@@ -37,7 +39,7 @@ def main():
         os.chmod(dst, 0o644)
 
     os.makedirs(os.path.join(HERE, "data", "freesasa"), exist_ok=True)
-    for pid in ALTLOC_IDS:
+    for pid in ALTLOC_IDS + HYDROGEN_IDS:
         for rel in (f"tests/data/freesasa_pdbs/{pid}.pdb", f"tests/data/freesasa_reference/{pid}.json"):
             dst = os.path.join(HERE, "data", "freesasa", os.path.basename(rel))
             shutil.copyfile(os.path.join(REF, rel), dst)

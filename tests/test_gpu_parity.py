@@ -419,6 +419,39 @@ def test_small_inputs_on_the_matrix_core_kernel(monkeypatch):
                 assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, w)), (w, n_points)
 
 
+def test_patch_test_of_the_many_point_kernel_on_cap_boundaries(monkeypatch):
+    """More than 128 points: whole tiles of 16 points (compact patches of the sphere) are dropped when ONE near
+    candidate's cap holds the patch (occlusion_mx.inc, patch test).  Caps of every size - a neighbour at distances
+    from touching to almost concentric, several radii, large and zero probes - put their rim across patches in every
+    way; tile counts that are not whole blocks of 64, point counts that are not whole tiles, with remainder points
+    in the last tile."""
+    import rustsasa_amd
+    monkeypatch.setenv("RSASA_OCCLUSION_KERNEL", "5")
+    rng = np.random.default_rng(77)
+    xs, ys, zs, rs, so = [], [], [], [], [0]
+    for d in np.linspace(0.05, 7.9, 160):          # pairs at growing distance, random direction
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        c0 = rng.uniform(-50, 50, 3)
+        pts = [c0, c0 + d * u]
+        if rng.random() < 0.5:                       # and sometimes a third atom nearby
+            pts.append(c0 + rng.normal(size=3) * 2.0)
+        for q in pts:
+            xs.append(q[0]); ys.append(q[1]); zs.append(q[2])
+            rs.append(rng.choice([1.2, 1.5, 1.88, 2.5, 0.7]))
+        so.append(len(xs))
+    x, y, z = (np.round(np.array(a), 3).astype(np.float32) for a in (xs, ys, zs))
+    r = np.array(rs, np.float32)
+    so = np.array(so, np.uint32)
+    for w in (8, 16):
+        with rustsasa_amd.Context(0, simd_width=w) as c:
+            for probe in (1.4, 0.0, 4.0):
+                for n_points in (129, 144, 145, 500, 960, 1030, 1344):
+                    got, _ = c.calculate_sasa_batch(x, y, z, r, None, so, probe, n_points)
+                    want = po.calculate_sasa_batch(x, y, z, r, None, so, probe, n_points, w, threads=0)
+                    assert np.array_equal(got, want), (w, probe, n_points, int(np.count_nonzero(got != want)))
+
+
 def test_matrix_core_kernel_hands_over_what_it_does_not_take(monkeypatch):
     """k_occlusion_mx takes atoms whose radii and probe keep its f16 operands, its three-step quotient and the
     remainder rule's error bound valid (probe in [0, 32], r + probe >= 0.5, r + max_r + 2 probe <= 64, every
