@@ -90,9 +90,51 @@ static const RadiiConfig &protor_map()
     return m;
 }
 
+// The same table as one open-addressing array keyed by the two names packed into 64 bits (residue names of the table
+// have at most 3 characters, atom names at most 4): one multiply and usually one probe per atom instead of two string
+// hashes.  Names that do not pack (longer) are not in the table.
+struct ProtorFlat {
+    static constexpr unsigned kBits = 11, kSize = 1u << kBits;  // 2048 slots for about 500 entries
+    std::uint64_t key[kSize];
+    float radius[kSize];
+    static bool pack(const char *res, size_t n_res, const char *atom, size_t n_atom, std::uint64_t *out)
+    {
+        if (n_res == 0 || n_res > 4 || n_atom == 0 || n_atom > 4) return false;
+        std::uint64_t k = 0;
+        for (size_t i = 0; i < n_res; i++) k |= (std::uint64_t)(unsigned char)res[i] << (8 * i);
+        for (size_t i = 0; i < n_atom; i++) k |= (std::uint64_t)(unsigned char)atom[i] << (32 + 8 * i);
+        *out = k;
+        return true;
+    }
+    static unsigned slot(std::uint64_t k) { return (unsigned)((k * 0x9E3779B97F4A7C15ull) >> (64 - kBits)); }
+    ProtorFlat()
+    {
+        for (auto &k : key) k = 0;  // (no packed name pair is 0)
+        for (const auto &e : kProtor) {
+            std::uint64_t k;
+            if (!pack(e.residue, std::strlen(e.residue), e.atom, std::strlen(e.atom), &k)) continue;
+            unsigned s = slot(k);
+            while (key[s] != 0 && key[s] != k) s = (s + 1) & (kSize - 1);
+            key[s] = k;
+            radius[s] = e.radius;
+        }
+    }
+    bool find(const std::string &res, const std::string &atom, float *out) const
+    {
+        std::uint64_t k;
+        if (!pack(res.data(), res.size(), atom.data(), atom.size(), &k)) return false;
+        for (unsigned s = slot(k); key[s] != 0; s = (s + 1) & (kSize - 1))
+            if (key[s] == k) { *out = radius[s]; return true; }
+        return false;
+    }
+};
+
 bool get_protor_radius(const std::string &residue, const std::string &atom, float *out)
 {
-    const auto &m = protor_map();
+    static const ProtorFlat flat;
+    if (flat.find(residue, atom, out)) return true;
+    if (residue.size() <= 4 && atom.size() <= 4 && !residue.empty() && !atom.empty()) return false;  // packs, not there
+    const auto &m = protor_map();  // (names the flat table cannot hold: the general lookup)
     auto r = m.find(residue);
     if (r == m.end()) return false;
     auto a = r->second.find(atom);
@@ -225,10 +267,44 @@ double parse_decimal(const char *p, size_t n)
     return std::strtod(std::string(b, (size_t)(e - b)).c_str(), nullptr);
 }
 
+// A %w.df field exactly as PDB writers print it - [spaces][-]digits '.' d digits, the point at its column: the same
+// integer / power-of-ten division as parse_decimal (so the same double, -0.0 included), without its scanning.  Anything
+// else (blank, exponent, shifted point, a sign without digits) returns false and takes the general path.
+inline bool fixed_decimal(const char *p, int w, int d, double &out)
+{
+    static const double pow10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6};
+    const int dot = w - d - 1;
+    if (p[dot] != '.') return false;
+    int i = 0;
+    while (i < dot && p[i] == ' ') i++;
+    bool neg = false;
+    if (i < dot && p[i] == '-') { neg = true; i++; }
+    if (i == dot) return false;
+    unsigned long long mant = 0;
+    for (; i < dot; i++) {
+        const unsigned c = (unsigned)(p[i] - '0');
+        if (c > 9) return false;
+        mant = mant * 10 + c;
+    }
+    for (i = dot + 1; i < w; i++) {
+        const unsigned c = (unsigned)(p[i] - '0');
+        if (c > 9) return false;
+        mant = mant * 10 + c;
+    }
+    const double v = (double)mant / pow10[d];
+    out = neg ? -v : v;
+    return true;
+}
+
+// columns [from, to] as a decimal; `decimals` > 0: try the fixed %w.df layout first
 template <typename Line>
-inline double column_decimal(const Line &line, size_t from, size_t to, double missing)
+inline double column_decimal(const Line &line, size_t from, size_t to, double missing, int decimals = 0)
 {
     if (line.size() < from) return missing;
+    if (decimals > 0 && line.size() >= to && to - from + 1 <= 12) {
+        double v;
+        if (fixed_decimal(line.data() + from - 1, (int)(to - from + 1), decimals, v)) return v;
+    }
     const size_t len = std::min(to, line.size()) - from + 1;
     const char *p = line.data() + from - 1;
     size_t i = 0;
@@ -341,7 +417,16 @@ struct ModelBuilder {
         std::pmr::vector<AtomRecord> &atoms = res.conformers[fi].atoms;
         if (atoms.capacity() == atoms.size()) atoms.reserve(std::max<size_t>(expect, 2 * atoms.size()));
         atoms.emplace_back();
+        last_atoms = &atoms;
         return atoms.back();
+    }
+    // one more record in the conformer of the previous add() (the caller knows that chain, residue, conformer are the
+    // same: a run of records with identical columns 17-27); no searches, no comparisons
+    std::pmr::vector<AtomRecord> *last_atoms = nullptr;
+    AtomRecord &add_to_last()
+    {
+        last_atoms->emplace_back();
+        return last_atoms->back();
     }
 };
 
@@ -420,6 +505,11 @@ Structure &Structure::operator=(Structure &&other) noexcept
 // line, residues and conformers a little more.
 static inline std::size_t pool_bytes_for(std::size_t text_bytes) { return text_bytes * 2 + 4096; }
 
+// process_files reads a file, selects its atoms and drops the model: unless radii come from the occupancy column,
+// nothing ever looks at occupancies or b-factors there, and two of a record's five decimals need not be converted
+// (they keep their defaults, 1.0 and 0.0).  Per thread; every other caller of the readers gets full records.
+static thread_local bool t_skip_occupancy_and_bfactor = false;
+
 Structure Structure::from_pdb_text(const std::string &text)
 {
     Structure s(pool_bytes_for(text.size()));
@@ -454,20 +544,25 @@ Structure Structure::from_pdb_text(const std::string &text)
             }
             run_len = run_left;
         }
+        const bool run_start = run_left == run_len;
         run_left--;
         const TextView name = field_view(line, 13, 16);
-        AtomRecord &rec = model.add(field_view(line, 22, 22), column_int(line, 23, 26, nullptr), field_view(line, 27, 27),
-                                    field_view(line, 18, 20), field_view(line, 17, 17), run_len);
+        // (the records of a run share columns 17-27: only its first one looks its conformer up)
+        AtomRecord &rec = run_start ? model.add(field_view(line, 22, 22), column_int(line, 23, 26, nullptr), field_view(line, 27, 27),
+                                                field_view(line, 18, 20), field_view(line, 17, 17), run_len)
+                                    : model.add_to_last();
         rec.hetero = is_het;
         bool serial_ok = false;
         const long sv = column_int(line, 7, 11, &serial_ok);
         rec.serial = serial_ok ? (std::size_t)sv : counter;
         rec.name.assign(name.first, name.second);
-        rec.x = column_decimal(line, 31, 38, 0.0);
-        rec.y = column_decimal(line, 39, 46, 0.0);
-        rec.z = column_decimal(line, 47, 54, 0.0);
-        rec.occupancy = column_decimal(line, 55, 60, 1.0);
-        rec.b_factor = column_decimal(line, 61, 66, 0.0);
+        rec.x = column_decimal(line, 31, 38, 0.0, 3);  // %8.3f
+        rec.y = column_decimal(line, 39, 46, 0.0, 3);
+        rec.z = column_decimal(line, 47, 54, 0.0, 3);
+        if (!t_skip_occupancy_and_bfactor) {
+            rec.occupancy = column_decimal(line, 55, 60, 1.0, 2);  // %6.2f
+            rec.b_factor = column_decimal(line, 61, 66, 0.0, 2);
+        }
         set_element(rec, field_view(line, 77, 78));
     }
     share_blank_conformers(s);
@@ -594,8 +689,10 @@ Structure Structure::from_mmcif_text(const std::string &text)
         rec.x = num(c_x, 0.0);
         rec.y = num(c_y, 0.0);
         rec.z = num(c_z, 0.0);
-        rec.occupancy = num(c_occ, 1.0);
-        rec.b_factor = num(c_b, 0.0);
+        if (!t_skip_occupancy_and_bfactor) {
+            rec.occupancy = num(c_occ, 1.0);
+            rec.b_factor = num(c_b, 0.0);
+        }
         set_element(rec, val(c_sym));
     }
     share_blank_conformers(s);
@@ -865,19 +962,25 @@ bool build_atom(const OptionValues &o, const AtomRecord &atom, const std::string
 // The atom loop shared by all four build_atoms_and_mapping bodies: chains ->
 // residues -> FIRST conformer -> atoms, hydrogen / HETATM filters.  `per_residue`
 // is told each residue's range of kept atoms.
+static const std::string kNoAltLoc;
+
 template <typename F>
 bool select_atoms(const Structure &pdb, const OptionValues &o, bool id_uses_altloc,
                   std::vector<rsasa_atom_t> &atoms, BuildError &err, F per_residue)
 {
+    atoms.reserve(atoms.size() + pdb.atom_count());  // (an upper bound: one allocation instead of a dozen regrowths)
     for (size_t ci = 0; ci < pdb.chains.size(); ci++) {
         const Chain &chain = pdb.chains[ci];
         for (size_t ri = 0; ri < chain.residues.size(); ri++) {
             const Residue &res = chain.residues[ri];
-            std::string residue_name;
-            if (!res.name(&residue_name)) {  // options.rs:161,248
+            // Residue::name(): Some(name) iff every conformer has the same name (options.rs:161,248); no copy
+            bool same_name = !res.conformers.empty();
+            for (size_t k = 1; k < res.conformers.size() && same_name; k++) same_name = res.conformers[k].name == res.conformers[0].name;
+            if (!same_name) {
                 err = {SASACalcError::FailedToGetResidueName, "Failed to get residue name"};
                 return false;
             }
+            const std::string &residue_name = res.conformers[0].name;
             const size_t begin = atoms.size();
             if (!res.conformers.empty()) {
                 const Conformer &conf = res.conformers.front();  // conformers().next()
@@ -886,10 +989,9 @@ bool select_atoms(const Structure &pdb, const OptionValues &o, bool id_uses_altl
                         err = {SASACalcError::ElementMissing, "Element missing for atom"};
                         return false;
                     }
-                    if (atom.element == "H" && !o.include_hydrogens) continue;  // options.rs:166
+                    if (!o.include_hydrogens && atom.element.size() == 1 && atom.element[0] == 'H') continue;  // options.rs:166
                     if (atom.hetero && !o.include_hetatms) continue;           // options.rs:169
-                    const std::uint64_t id =
-                        fnv_hash_altloc_serial(id_uses_altloc ? conf.alt_loc : std::string(), atom.serial);
+                    const std::uint64_t id = fnv_hash_altloc_serial(id_uses_altloc ? conf.alt_loc : kNoAltLoc, atom.serial);
                     if (!build_atom(o, atom, residue_name, id, atoms, err)) return false;
                 }
             }
@@ -1365,9 +1467,12 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
         parallel_for(c->n, host_threads, [&](size_t k) {
             const size_t i = order[k].second;
             try {
+                t_skip_occupancy_and_bfactor = !o.read_radii_from_occupancy;
                 c->pdbs[i] = Structure::open(paths[base + i]);
+                t_skip_occupancy_and_bfactor = false;
                 c->prep[i] = prepare<Level>(c->pdbs[i], o);
             } catch (const std::exception &e) {  // unreadable file: report, keep going (main.rs:446-454)
+                t_skip_occupancy_and_bfactor = false;
                 c->prep[i] = Prepared{};
                 c->prep[i].err = {SASACalcError::Engine, std::string("cannot read structure: ") + e.what()};
             }

@@ -40,6 +40,14 @@ int main(void)
     if (out[0] < exposed * 0.99 || out[0] > exposed * 1.01) return 17;
     if (out[1] < exposed * 0.99 || out[1] > exposed * 1.01) return 18;
     if (out[2] < full * 0.999 || out[2] > full * 1.001) return 19;
+    /* ABI 2: lane count round trip, NUMA binding of the calling thread (node -1: nothing to bind), wait-all with
+     * nothing in flight */
+    int w = 0, node = -2;
+    if (rsasa_context_set_simd_width(ctx, 4) != RSASA_OK || rsasa_context_get_simd_width(ctx, &w) != RSASA_OK || w != 4) return 23;
+    if (rsasa_context_set_simd_width(ctx, 3) != RSASA_ERR_INVALID_ARGUMENT) return 24;
+    if (rsasa_context_set_simd_width(ctx, 8) != RSASA_OK) return 25;
+    if (rsasa_context_bind_thread(ctx, &node) != RSASA_OK || node < -1) return 26;
+    if (rsasa_batch_wait_all(ctx) != RSASA_OK || rsasa_batch_wait(ctx) != RSASA_OK) return 27;
     /* empty input is valid and touches nothing */
     if (rsasa_calculate_sasa_internal(ctx, NULL, 0, 1.4f, 100, 1, NULL) != RSASA_OK) return 20;
     /* invalid arguments are reported, not crashed on */

@@ -306,6 +306,49 @@ def test_process_files_companion_context_runs_with_the_callers_settings(tmp_path
     assert np.array_equal(np.array(got["results"][i_cif], np.float32), res)
 
 
+@pytest.mark.gpu
+def test_process_files_with_radii_from_occupancy_reads_the_occupancies(tmp_path):
+    """Directory mode skips the conversion of occupancy / b-factor columns unless an option needs them
+    (host_api.cpp t_skip_occupancy_and_bfactor): with radii from the occupancy column the values must be the
+    single-file results of the same option."""
+    paths = [sio.data_path(n) for n in ("1jcd.pdb", "151L_H3.pdb", "example.cif")]
+    lst = str(tmp_path / "files.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    p = subprocess.run([CLI, "files", "residue", lst, "--full", "--read-radii-from-occupancy"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:500]
+    got = json.loads(p.stdout)
+    assert got["n_ok"] == len(paths)
+    for path, r in zip(paths, got["results"]):
+        single = run_cli("residue", os.path.basename(path), "--read-radii-from-occupancy")["Residue"]
+        assert np.array_equal(np.array(r, np.float32), np.array([x["value"] for x in single], np.float32)), path
+
+
+def test_fixed_column_decimals_equal_the_general_parser(tmp_path):
+    """The PDB reader takes %8.3f / %6.2f fields through a fixed-layout fast path (integer / power of ten, as Clinger's
+    exact case) and everything else through the general parser / strtod: both must give the double Python's float()
+    gives, for well-formed fields, shifted points, exponents, signs without digits, negative zero.  No GPU: the
+    selection (`select --read-radii-from-occupancy`) prints x, y, z and the occupancy-as-radius as f32."""
+    coords = ["  -0.000", "9999.999", "-999.999", "   0.001", "  1.2345", " 1.5e+01", "   -.500", "     12.", "  12.000",
+              "-123.456", "   7.100", "0012.500", "  +3.250", "    3.25", " 100.0  "]
+    occs = ["  1.00", " -0.50", "  0.5 ", "  .750", " 12.34", "1.0e-1", "  2.  ", "  0.00", " -0.00", "  9.99"]
+    lines = []
+    for k, c in enumerate(coords):
+        o = occs[k % len(occs)]
+        y, z = coords[(k + 3) % len(coords)], coords[(k + 7) % len(coords)]
+        lines.append("ATOM  %5d  CA  ALA A%4d    %s%s%s%s  0.00           C  " % (k + 1, k + 1, c, y, z, o))
+    path = tmp_path / "fields.pdb"
+    path.write_text("\n".join(lines) + "\nEND\n")
+    p = subprocess.run([CLI, "select", str(path), "--read-radii-from-occupancy"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:500]
+    atoms = json.loads(p.stdout)["atoms"]
+    assert len(atoms) == len(coords)
+    for k, a in enumerate(atoms):
+        want = [coords[k], coords[(k + 3) % len(coords)], coords[(k + 7) % len(coords)], occs[k % len(occs)]]
+        for got, text in zip(a[:4], want):
+            w = np.float32(float(text))
+            assert np.float32(got) == w, (k, text, got)  # (the JSON number "-0" reads back as an int: no sign check on zeros)
+
+
 # ---- writers (reference src/utils/io.rs) ---------------------------------------------
 
 @pytest.mark.parametrize("name", ["1jcd.pdb", "151L_H3.pdb", "2drt.pdb"])
