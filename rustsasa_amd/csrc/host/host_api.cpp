@@ -121,17 +121,27 @@ struct ProtorFlat {
     }
     bool find(const std::string &res, const std::string &atom, float *out) const
     {
+        return find(res.data(), res.size(), atom.data(), atom.size(), out);
+    }
+    bool find(const char *res, size_t n_res, const char *atom, size_t n_atom, float *out) const
+    {
         std::uint64_t k;
-        if (!pack(res.data(), res.size(), atom.data(), atom.size(), &k)) return false;
+        if (!pack(res, n_res, atom, n_atom, &k)) return false;
         for (unsigned s = slot(k); key[s] != 0; s = (s + 1) & (kSize - 1))
             if (key[s] == k) { *out = radius[s]; return true; }
         return false;
     }
 };
 
-bool get_protor_radius(const std::string &residue, const std::string &atom, float *out)
+static const ProtorFlat &protor_flat()
 {
     static const ProtorFlat flat;
+    return flat;
+}
+
+bool get_protor_radius(const std::string &residue, const std::string &atom, float *out)
+{
+    const ProtorFlat &flat = protor_flat();
     if (flat.find(residue, atom, out)) return true;
     if (residue.size() <= 4 && atom.size() <= 4 && !residue.empty() && !atom.empty()) return false;  // packs, not there
     const auto &m = protor_map();  // (names the flat table cannot hold: the general lookup)
@@ -699,9 +709,9 @@ Structure Structure::from_mmcif_text(const std::string &text)
     return s;
 }
 
-Structure Structure::open(const std::string &path)
+// the whole file in a buffer the thread keeps (no stream, no copies of the text)
+static const std::string &read_whole_file(const std::string &path)
 {
-    // one read into a buffer the thread keeps (no stream, no copies of the text)
     static thread_local std::string text;
     std::FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("cannot open " + path);
@@ -722,8 +732,19 @@ Structure Structure::open(const std::string &path)
     std::fclose(f);
     if (bad) throw std::runtime_error("cannot read " + path);
     text.resize(got);
+    return text;
+}
+
+static bool is_mmcif_path(const std::string &path)
+{
     const std::string ext = upper(path.substr(path.find_last_of('.') == std::string::npos ? path.size() : path.find_last_of('.')));
-    if (ext == ".CIF" || ext == ".MMCIF") return from_mmcif_text(text);
+    return ext == ".CIF" || ext == ".MMCIF";
+}
+
+Structure Structure::open(const std::string &path)
+{
+    const std::string &text = read_whole_file(path);
+    if (is_mmcif_path(path)) return from_mmcif_text(text);
     return from_pdb_text(text);
 }
 
@@ -1055,7 +1076,162 @@ Prepared prepare<ProteinLevel>(const Structure &pdb, const OptionValues &o)
     return p;
 }
 
+// ---- directory mode's short cut: PDB text -> kept atoms, without the atom records of the model ----
+// process_files reads a file, selects its atoms and throws the model away; building 112-byte atom records with two
+// strings each only to walk them once is most of its CPU time.  For PLAIN files - one conformer per residue (no
+// alternate-location characters), the records of a chain and of a residue contiguous and in ascending residue order,
+// every radius found - this reads the text once and writes what prepare<Level> would have written: the kept atoms
+// (same order, same f64 -> f32 coordinates, same radii, same ids) and the segment ends, plus a model WITHOUT atoms
+// (chains, residues, one named conformer each) for the result's metadata.  Anything else - an alt-loc, a chain or
+// residue that comes back, a short record, a missing radius or element, a custom radii table - returns false and the
+// file takes the general reader, which also produces the errors.  tests/test_host_api.py compares the two on every
+// fixture and on mutated files (`sasa_host_cli prepare`); RSASA_NO_FAST_READER=1 switches it off.
+enum class SegKind { None, Residue, Chain };
+template <typename Level> struct seg_kind_of;
+template <> struct seg_kind_of<AtomLevel> { static constexpr SegKind value = SegKind::None; };
+template <> struct seg_kind_of<ResidueLevel> { static constexpr SegKind value = SegKind::Residue; };
+template <> struct seg_kind_of<ChainLevel> { static constexpr SegKind value = SegKind::Chain; };
+template <> struct seg_kind_of<ProteinLevel> { static constexpr SegKind value = SegKind::Residue; };
+
+bool fast_pdb_prepare(const std::string &text, const OptionValues &o, SegKind kind, Structure &light, Prepared &p)
+{
+    if (o.radii_config) return false;
+    const ProtorFlat &protor = protor_flat();
+    std::pmr::memory_resource *const mem = light.chains.get_allocator().resource();
+    p.atoms.clear();
+    p.seg_end.clear();
+    p.atoms.reserve(text.size() / 80 + 1);
+    bool in_first_model = true, seen_model = false;
+    std::size_t counter = 0;
+    const char *key = nullptr;             // columns 17-27 of the current residue's records
+    std::int64_t res_seq = 0;              // the current residue (of the current chain)
+    const char *cur = text.data(), *const end = text.data() + text.size();
+    while (cur < end) {
+        const LineView line = next_line(cur, end);
+        const bool is_atom = line.n >= 6 && std::memcmp(line.p, "ATOM  ", 6) == 0;
+        const bool is_het = !is_atom && line.n >= 6 && std::memcmp(line.p, "HETATM", 6) == 0;
+        if (!(is_atom || is_het)) {
+            if (line.starts_with("MODEL")) {
+                if (seen_model) in_first_model = false;
+                seen_model = true;
+            } else if (line.starts_with("ENDMDL")) {
+                in_first_model = false;
+            }
+            continue;
+        }
+        if (!in_first_model) continue;
+        if (line.n < 54 || line.p[16] != ' ') return false;  // short record / alternate location: the general reader
+        counter++;
+        if (!key || std::memcmp(line.p + 16, key, 11) != 0) {
+            // a new residue: it must continue the current chain in ascending order, or open a chain not seen before
+            const TextView chain_id = field_view(line, 22, 22), icode = field_view(line, 27, 27), res_name = field_view(line, 18, 20);
+            const std::int64_t seq = column_int(line, 23, 26, nullptr);
+            const bool same_chain = !light.chains.empty() && same(light.chains.back().id, chain_id);
+            if (same_chain) {
+                const Residue &prev = light.chains.back().residues.back();
+                const int c = prev.insertion_code.compare(0, std::string::npos, icode.first, icode.second);
+                if (!(seq > res_seq || (seq == res_seq && c < 0))) return false;
+            } else {
+                for (const Chain &ch : light.chains)
+                    if (same(ch.id, chain_id)) return false;
+                if (kind == SegKind::Chain && !light.chains.empty()) p.seg_end.push_back((uint32_t)p.atoms.size());
+                light.chains.push_back(Chain{std::string(chain_id.first, chain_id.second), std::pmr::vector<Residue>(mem)});
+            }
+            if (kind == SegKind::Residue && key) p.seg_end.push_back((uint32_t)p.atoms.size());
+            Chain &chain = light.chains.back();
+            chain.residues.push_back(Residue{seq, std::string(icode.first, icode.second), std::pmr::vector<Conformer>(mem)});
+            chain.residues.back().conformers.push_back(
+                Conformer{std::string(res_name.first, res_name.second), std::string(), std::pmr::vector<AtomRecord>(mem)});
+            key = line.p + 16;
+            res_seq = seq;
+        }
+        // element (columns 77-78, upper case; else the first letter of the name), hydrogen / HETATM filters
+        const TextView name = field_view(line, 13, 16), sym = field_view(line, 77, 78);
+        char e0 = 0, e1 = 0;
+        if (sym.second) {
+            e0 = (char)std::toupper((unsigned char)sym.first[0]);
+            if (sym.second > 1) e1 = (char)std::toupper((unsigned char)sym.first[1]);
+        } else {
+            for (size_t k = 0; k < name.second && !e0; k++)
+                if (std::isalpha((unsigned char)name.first[k])) e0 = (char)std::toupper((unsigned char)name.first[k]);
+        }
+        if (!e0) return false;                                            // options.rs:164 (the general path reports it)
+        if (!o.include_hydrogens && e0 == 'H' && !e1) continue;          // options.rs:166
+        if (is_het && !o.include_hetatms) continue;                      // options.rs:169
+        float radius = 0.f;
+        if (o.read_radii_from_occupancy) {
+            radius = (float)column_decimal(line, 55, 60, 1.0, 2);        // options.rs:83-84
+        } else {
+            const Conformer &conf = light.chains.back().residues.back().conformers.front();
+            if (!protor.find(conf.name.data(), conf.name.size(), name.first, name.second, &radius)) {
+                if (!o.allow_vdw_fallback) return false;
+                const std::string el = e1 ? std::string{e0, e1} : std::string(1, e0);
+                if (!vdw_radius(el, &radius)) return false;
+            }
+        }
+        bool serial_ok = false;
+        const long sv = column_int(line, 7, 11, &serial_ok);
+        rsasa_atom_t a;
+        a.position[0] = (float)column_decimal(line, 31, 38, 0.0, 3);     // options.rs:106-110: f64 -> f32
+        a.position[1] = (float)column_decimal(line, 39, 46, 0.0, 3);
+        a.position[2] = (float)column_decimal(line, 47, 54, 0.0, 3);
+        a.radius = radius;
+        a.id = fnv_hash_altloc_serial(kNoAltLoc, serial_ok ? (std::size_t)sv : counter);
+        p.atoms.push_back(a);
+    }
+    if (kind == SegKind::Residue && key) p.seg_end.push_back((uint32_t)p.atoms.size());
+    if (kind == SegKind::Chain && !light.chains.empty()) p.seg_end.push_back((uint32_t)p.atoms.size());
+    return true;
+}
+
 }  // namespace
+
+// Test hook (sasa_host_cli prepare): what directory mode hands to the GPU for one file - kept atoms, segment ends - and
+// the model its results take their metadata from, through the short cut (`fast`, when the file qualifies) or the
+// general reader.  JSON text; no GPU.
+std::string debug_prepare_json(const std::string &path, const OptionValues &o, int level, bool fast)
+{
+    const std::string &text = read_whole_file(path);
+    Structure model;
+    Prepared p;
+    bool used_fast = false;
+    const SegKind kinds[] = {SegKind::None, SegKind::Residue, SegKind::Chain, SegKind::Residue};
+    if (fast && !is_mmcif_path(path)) {
+        Structure light(text.size() / 8 + 4096);
+        if (fast_pdb_prepare(text, o, kinds[level], light, p)) {
+            model = std::move(light);
+            used_fast = true;
+        }
+    }
+    if (!used_fast) {
+        model = is_mmcif_path(path) ? Structure::from_mmcif_text(text) : Structure::from_pdb_text(text);
+        p = level == 0 ? prepare<AtomLevel>(model, o) : level == 1 ? prepare<ResidueLevel>(model, o)
+          : level == 2 ? prepare<ChainLevel>(model, o) : prepare<ProteinLevel>(model, o);
+    }
+    char buf[160];
+    std::string out = std::string("{\"fast\":") + (used_fast ? "true" : "false") + ",\"error\":" + std::to_string((int)p.err.error) + ",\"atoms\":[";
+    for (size_t i = 0; i < p.atoms.size(); i++) {
+        const rsasa_atom_t &a = p.atoms[i];
+        std::snprintf(buf, sizeof buf, "%s[\"%a\",\"%a\",\"%a\",\"%a\",\"%llu\"]", i ? "," : "", a.position[0], a.position[1], a.position[2],
+                      a.radius, (unsigned long long)a.id);
+        out += buf;
+    }
+    out += "],\"seg_end\":[";
+    for (size_t i = 0; i < p.seg_end.size(); i++) out += (i ? "," : "") + std::to_string(p.seg_end[i]);
+    out += "],\"model\":[";
+    for (size_t c = 0; c < model.chains.size(); c++) {
+        out += (c ? ",[\"" : "[\"") + model.chains[c].id + "\",[";
+        for (size_t r = 0; r < model.chains[c].residues.size(); r++) {
+            const Residue &res = model.chains[c].residues[r];
+            std::string name;
+            const bool named = res.name(&name);
+            out += (r ? ",[" : "[") + std::to_string(res.serial_number) + ",\"" + res.insertion_code + "\",\"" + (named ? name : std::string("?")) + "\"]";
+        }
+        out += "]]";
+    }
+    out += "]}";
+    return out;
+}
 
 // (public, see the header) the ChainLevel selection of one structure without any GPU work
 Result<SelectedAtoms> select_by_chain(const Structure &pdb, const OptionValues &o)
@@ -1310,6 +1486,7 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // (chunks of 512 files and two GPU workers: 16.4 k files/s on the 4 363-file set against 13.3 k with 256 and one
     // shared context - fewer per-chunk joins of the parse pool, and one chunk's upload beside the other's kernels)
     if (files_per_batch == 0) files_per_batch = 512;
+    const bool fast_reader = std::getenv("RSASA_NO_FAST_READER") == nullptr;
     // one worker per given context; with a single context a second, private one on the same device joins it
     // for the duration of the call (calls on one context are serialised)
     std::vector<rsasa_context_t *> contexts = o.contexts;
@@ -1467,8 +1644,18 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
         parallel_for(c->n, host_threads, [&](size_t k) {
             const size_t i = order[k].second;
             try {
+                const std::string &text = read_whole_file(paths[base + i]);
+                const bool cif = is_mmcif_path(paths[base + i]);
+                if (fast_reader && !cif) {  // plain PDB files: kept atoms straight from the text (fast_pdb_prepare)
+                    Structure light(text.size() / 8 + 4096);
+                    if (fast_pdb_prepare(text, o, seg_kind_of<Level>::value, light, c->prep[i])) {
+                        c->pdbs[i] = std::move(light);
+                        return;
+                    }
+                    c->prep[i] = Prepared{};
+                }
                 t_skip_occupancy_and_bfactor = !o.read_radii_from_occupancy;
-                c->pdbs[i] = Structure::open(paths[base + i]);
+                c->pdbs[i] = cif ? Structure::from_mmcif_text(text) : Structure::from_pdb_text(text);
                 t_skip_occupancy_and_bfactor = false;
                 c->prep[i] = prepare<Level>(c->pdbs[i], o);
             } catch (const std::exception &e) {  // unreadable file: report, keep going (main.rs:446-454)

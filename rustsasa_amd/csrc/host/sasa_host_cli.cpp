@@ -273,6 +273,12 @@ int main(int argc, char **argv)
                             a.radius, (unsigned long long)a.id);
             }
             std::printf("]}\n");
+        } else if (level == "prepare-fast" || level == "prepare-general") {
+            // directory mode's per-file work without a GPU: `--level N` (0 atom, 1 residue, 2 chain, 3 protein)
+            int lv = 1;
+            for (int i = 3; i + 1 < argc; i++)
+                if (!std::strcmp(argv[i], "--level")) lv = std::atoi(argv[i + 1]);
+            std::printf("%s\n", detail::debug_prepare_json(argv[2], make<ChainLevel>(argc, argv).values(), lv, level == "prepare-fast").c_str());
         } else if (level == "rewrite") {  // reader -> writer round trip, no GPU
             std::printf("%s", pdb.to_pdb_text().c_str());
         } else if (level == "parse") {  // reader only (no GPU): atom / residue / chain counts

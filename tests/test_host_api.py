@@ -323,6 +323,63 @@ def test_process_files_with_radii_from_occupancy_reads_the_occupancies(tmp_path)
         assert np.array_equal(np.array(r, np.float32), np.array([x["value"] for x in single], np.float32)), path
 
 
+def _prepare_json(path, level, fast, *opts):
+    p = subprocess.run([CLI, "prepare-fast" if fast else "prepare-general", str(path), "--level", str(level), *opts],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:300]
+    return json.loads(p.stdout)
+
+
+def test_directory_modes_short_cut_equals_the_general_reader(tmp_path):
+    """process_files reads plain PDB files straight into the kept atoms (host_api.cpp fast_pdb_prepare) and leaves
+    everything else to the general reader + selection.  Both must hand the GPU the same atoms (bit patterns of x, y, z,
+    radius; ids), the same segment ends and the same result metadata - on the fixtures, under the options the
+    reference tests, and on mutants that hit each of the short cut's exits (alternate locations, chains and residues
+    that come back, descending numbers, short records, missing elements and radii, several models)."""
+    rng = np.random.default_rng(5)
+    names = ["151L_H3.pdb", "bad_seqadv_1A06.pdb", "1jcd.pdb", "2drt.pdb", "freesasa/2gpi.pdb", "freesasa/4c1a.pdb"]
+    option_sets = [(), ("--include-hetatms", "--allow-vdw-fallback"), ("--include-hydrogens", "--allow-vdw-fallback"),
+                   ("--read-radii-from-occupancy",)]
+    n_fast = n_cases = 0
+
+    def compare(path, label):
+        nonlocal n_fast, n_cases
+        for level in (0, 1, 2, 3):
+            for opts in option_sets:
+                a, b = _prepare_json(path, level, True, *opts), _prepare_json(path, level, False, *opts)
+                n_fast += a.pop("fast")
+                b.pop("fast")
+                n_cases += 1
+                assert a == b, (label, level, opts, len(a["atoms"]), len(b["atoms"]), a["error"], b["error"])
+
+    for name in names:
+        compare(sio.data_path(name), name)
+        lines = open(sio.data_path(name)).read().split("\n")
+        atom_idx = [i for i, l in enumerate(lines) if l.startswith(("ATOM  ", "HETATM"))]
+        for m in range(14):
+            mut = list(lines)
+            i = int(rng.choice(atom_idx[5:-5]))
+            kind = m % 14
+            if kind == 0:   mut[i] = mut[i][:16] + "A" + mut[i][17:]                       # an alternate location
+            elif kind == 1: mut[i] = mut[i][:21] + "Z" + mut[i][22:]                       # a one-atom chain in the middle
+            elif kind == 2: mut[i], mut[i + 1] = mut[i + 1], mut[i]                         # two records swapped
+            elif kind == 3: mut[i] = mut[i][:40]                                            # a short record
+            elif kind == 4: mut[i] = mut[i][:76] + "  " + mut[i][78:]                       # no element symbol
+            elif kind == 5: mut[i] = mut[i][:12] + " XX " + mut[i][16:]                     # an atom name without a radius
+            elif kind == 6: mut.insert(i, "ENDMDL"); mut.insert(i + 1, "MODEL        2")    # a second model
+            elif kind == 7: mut[i] = mut[i][:22] + "%4d" % 1 + mut[i][26:]                  # a residue number that goes back
+            elif kind == 8: mut[i] = mut[i][:17] + "GLY" + mut[i][20:]                      # another name inside a residue
+            elif kind == 9: mut[i] = mut[i][:26] + "B" + mut[i][27:]                        # an insertion code
+            elif kind == 10: mut[i] = mut[i][:6] + "  abc" + mut[i][11:]                    # a serial number that is not one
+            elif kind == 11: mut[i] = "HETATM" + mut[i][6:]                                 # a HETATM inside a residue
+            elif kind == 12: mut[i] = mut[i][:20] + "x" + mut[i][21:]                       # a character in column 21
+            elif kind == 13: mut = mut[:i] + mut[atom_idx[2]:atom_idx[8]] + mut[i:]         # an early residue repeated later
+            path = tmp_path / f"mut_{os.path.basename(name)}_{m}.pdb"
+            path.write_text("\n".join(mut))
+            compare(path, f"{name} mutant {kind}")
+    assert n_fast > 40 and n_cases - n_fast > 40, (n_fast, n_cases)  # both routes were exercised
+
+
 def test_fixed_column_decimals_equal_the_general_parser(tmp_path):
     """The PDB reader takes %8.3f / %6.2f fields through a fixed-layout fast path (integer / power of ten, as Clinger's
     exact case) and everything else through the general parser / strtod: both must give the double Python's float()
