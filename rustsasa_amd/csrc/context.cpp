@@ -331,7 +331,7 @@ struct rsasa_context {
     // workspace 0.
     struct Workspace {
         DeviceBuffer segments, acc, grids, grid_sums, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums,
-            sorted_xyzr, sorted_orig, sorted_id, sorted_id32, status, atom_sasa;
+            sorted_xyzr, sorted_orig, sorted_id, sorted_id32, status, atom_sasa, claim;
         hipEvent_t ev[5] = {};  // timing (rsasa_context_enable_timing): start, grid built, occlusion starts / has run, sums done
         hipEvent_t ev_occ = nullptr;  // the batch's occlusion kernels have run (the other workspace's batch starts its own
         bool occ_recorded = false;    // behind it: two occlusion kernels sharing the CUs only slow each other down)
@@ -349,7 +349,7 @@ struct rsasa_context {
                  &sid_sorted = ws[0].sid_sorted, &deferred_list = ws[0].deferred_list, &cell_of = ws[0].cell_of,
                  &rank_of = ws[0].rank_of, &cells = ws[0].cells, &windows = ws[0].windows, &scan_sums = ws[0].scan_sums,
                  &sorted_xyzr = ws[0].sorted_xyzr, &sorted_orig = ws[0].sorted_orig, &sorted_id = ws[0].sorted_id,
-                 &sorted_id32 = ws[0].sorted_id32, &status = ws[0].status, &atom_sasa = ws[0].atom_sasa;
+                 &sorted_id32 = ws[0].sorted_id32, &status = ws[0].status, &atom_sasa = ws[0].atom_sasa, &claim = ws[0].claim;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
     // further input / output slots of the pipelined host-buffer path (kSlots sub-batches in flight)
@@ -630,6 +630,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, W.grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
     if ((rc = reserve(ctx, W.sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, W.deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
+    if ((rc = reserve(ctx, W.claim, kClaimBytes))) return rc;
     if (has_tail && (rc = reserve(ctx, W.cell_of, std::max<size_t>(N, 1) * 4))) return rc;  // (batch-wide binning only)
     if ((rc = reserve(ctx, W.rank_of, std::max<size_t>(N, 1) * 4))) return rc;
     // + 1 end marker, + 3: k_zero_cells / k_scan_* access whole 16-byte vectors up to the end marker
@@ -637,7 +638,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     // one k_sort_window workgroup per window of kWindowCells 16-bit cell entries (two per entry of the cell
     // array), at most one partly filled window per structure: whatever fits the cell array fits this list
     const uint64_t window_capacity = std::min<uint64_t>(2 * ctx->cell_capacity / kWindowCells + S + 1, 0x7FFFFFFFull);
-    if ((rc = reserve(ctx, W.windows, (size_t)window_capacity * sizeof(uint2)))) return rc;
+    if ((rc = reserve(ctx, W.windows, (size_t)window_capacity * sizeof(uint4)))) return rc;
     if ((rc = reserve(ctx, W.scan_sums, kScanBlocks * 4))) return rc;
     if ((rc = reserve(ctx, W.sorted_xyzr, std::max<size_t>(N, 1) * 16))) return rc;
     if ((rc = reserve(ctx, W.sorted_orig, std::max<size_t>(N, 1) * 4))) return rc;
@@ -668,11 +669,12 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.grid_sums = (GridSums *)W.grid_sums.p;
     v.sid_sorted = (uint32_t *)W.sid_sorted.p;
     v.deferred_list = (uint32_t *)W.deferred_list.p;
+    v.claim = (uint32_t *)W.claim.p;
     v.cell_of = (uint32_t *)W.cell_of.p;
     v.rank_of = (uint32_t *)W.rank_of.p;
     v.cells = (uint32_t *)W.cells.p;
     v.cell_capacity = ctx->cell_capacity;
-    v.windows = (uint2 *)W.windows.p;
+    v.windows = (uint4 *)W.windows.p;
     v.window_capacity = (uint32_t)window_capacity;
     v.scan_block_sums = (uint32_t *)W.scan_sums.p;
     v.sorted_xyzr = (float4 *)W.sorted_xyzr.p;
@@ -934,7 +936,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->windows, &ctx->scan_sums, &ctx->sorted_xyzr,
-                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa,
+                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa, &ctx->claim,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
                             &ctx->in3_x, &ctx->in3_y, &ctx->in3_z, &ctx->in3_r, &ctx->in3_id, &ctx->in3_res,
@@ -961,7 +963,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
         rsasa_context::Workspace &w1 = ctx->ws[1];
         for (DeviceBuffer *b : {&w1.segments, &w1.acc, &w1.grids, &w1.grid_sums, &w1.sid_sorted, &w1.deferred_list, &w1.cell_of, &w1.rank_of,
                                 &w1.cells, &w1.windows, &w1.scan_sums, &w1.sorted_xyzr, &w1.sorted_orig, &w1.sorted_id, &w1.sorted_id32,
-                                &w1.status, &w1.atom_sasa})
+                                &w1.status, &w1.atom_sasa, &w1.claim})
             release(*b);
     }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -1185,7 +1187,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     const size_t N = so[S];
     if (N == 0 || N > kSmallAtoms) return kNotSmall;
     std::vector<StructGrid> grids(S);
-    std::vector<uint2> windows;  // work list of k_sort_window (the general path builds it on the device)
+    std::vector<uint4> windows;  // work list of k_sort_window (the general path builds it on the device)
     unsigned long long total_cells = 0;  // 16-bit entries of the cell array
     for (size_t s = 0; s < S; s++) {
         if (so[s] > so[s + 1]) return kNotSmall;  // (the general path reports it)
@@ -1208,7 +1210,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
         grids[s].sorted_base = so[s];
         grids[s].cell_base = (uint32_t)total_cells;
         total_cells += lds_cell_slots(grids[s].n_cells);
-        for (uint32_t w = 0; w < grid_windows(grids[s].n_cells); w++) windows.push_back(make_uint2((uint32_t)s, w));
+        for (uint32_t w = 0; w < grid_windows(grids[s].n_cells); w++) windows.push_back(make_uint4((uint32_t)s, w, grids[s].atom_begin, grids[s].n_atoms));
     }
     const unsigned long long tail_begin = (total_cells / 2ull + 1023ull) & ~1023ull;
     const size_t W = windows.size();
@@ -1218,7 +1220,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if (rc) return rc;
     // staging layout (16-byte aligned sections): status | grids | windows | x | y | z | r | id | residue offsets
     auto up = [](size_t v) { return (v + 15) & ~size_t(15); };
-    const size_t o_grid = 64, o_win = o_grid + S * sizeof(StructGrid), o_x = o_win + up(W * sizeof(uint2)), o_y = o_x + up(N * 4), o_z = o_y + up(N * 4),
+    const size_t o_grid = 64, o_win = o_grid + up(S * sizeof(StructGrid)), o_x = o_win + up(W * sizeof(uint4)), o_y = o_x + up(N * 4), o_z = o_y + up(N * 4),
                  o_r = o_z + up(N * 4), o_id = o_r + up(N * 4), o_res = o_id + (id ? up(N * 8) : 0),
                  in_bytes = o_res + (R ? up((R + 1) * 4) : 0);
     const size_t o_oa = 0, o_or = up(N * 4), out_bytes = o_or + up(R * 4);
@@ -1237,6 +1239,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     if ((rc = reserve(ctx, ctx->small_out, out_bytes))) return rc;
     if ((rc = reserve(ctx, ctx->sid_sorted, N * 4))) return rc;
     if ((rc = reserve(ctx, ctx->deferred_list, N * 4))) return rc;
+    if ((rc = reserve(ctx, ctx->claim, kClaimBytes))) return rc;
     if ((rc = reserve(ctx, ctx->rank_of, N * 4))) return rc;
     if ((rc = reserve(ctx, ctx->cells, (size_t)(tail_begin + 8) * 4))) return rc;
     if ((rc = reserve(ctx, ctx->sorted_xyzr, N * 16))) return rc;
@@ -1253,7 +1256,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     stt.n_windows = (uint32_t)W;
     std::memcpy(h, &stt, sizeof stt);
     std::memcpy(h + o_grid, grids.data(), S * sizeof(StructGrid));
-    if (W) std::memcpy(h + o_win, windows.data(), W * sizeof(uint2));
+    if (W) std::memcpy(h + o_win, windows.data(), W * sizeof(uint4));
     std::memcpy(h + o_x, x, N * 4);
     std::memcpy(h + o_y, y, N * 4);
     std::memcpy(h + o_z, z, N * 4);
@@ -1280,11 +1283,12 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
     v.status = (BatchStatus *)d;
     v.sid_sorted = (uint32_t *)ctx->sid_sorted.p;
     v.deferred_list = (uint32_t *)ctx->deferred_list.p;
+    v.claim = (uint32_t *)ctx->claim.p;
     v.cell_of = (uint32_t *)ctx->cell_of.p;
     v.rank_of = (uint32_t *)ctx->rank_of.p;
     v.cells = (uint32_t *)ctx->cells.p;
     v.cell_capacity = tail_begin + 8;
-    v.windows = (uint2 *)(d + o_win);
+    v.windows = (uint4 *)(d + o_win);
     v.window_capacity = (uint32_t)W;
     v.sorted_xyzr = (float4 *)ctx->sorted_xyzr.p;
     v.sorted_orig = (uint32_t *)ctx->sorted_orig.p;

@@ -46,6 +46,12 @@ struct Segment {
 };
 
 // Deferred status of a batch, written on device, copied to pinned host memory.
+// k_occlusion_mx's waves claim blocks of atoms from one counter per XCD piece of the launch's range; every counter has
+// a 128-byte line to itself (all of them in one line made every claim of the GPU queue up behind one address), and
+// the launch over the tail structures has its own set.
+constexpr uint32_t kClaimStride = 32;                       // uint32 entries between two counters
+constexpr uint32_t kClaimBytes = 2u * 8u * kClaimStride * 4u;
+
 struct BatchStatus {
     uint32_t overflow;        // total cells exceed the workspace capacity: re-run after growing
     uint32_t grid_too_large;  // some structure needs more than 2^31 cells
@@ -97,9 +103,10 @@ struct BatchView {
     uint32_t *cell_of, *rank_of;  // binning only.  Batch-wide route: cell index / arrival rank inside the cell;
                                   // k_sort_window: rank_of = sorted position of the atoms a workgroup's registers do not hold
     uint32_t *deferred_list;      // atoms k_occlusion_fast left to the general kernel (BatchStatus::deferred entries)
+    uint32_t *claim;              // k_occlusion_mx: block counters of its persistent waves, kClaimBytes (launch_occlusion zeroes them)
     uint32_t *cells;              // cell starts (cell_capacity + 1 entries of 32 bits; see StructGrid::cell_base)
     uint64_t cell_capacity;
-    uint2 *windows;               // (structure, window) of every k_sort_window workgroup
+    uint4 *windows;               // (structure, window, first atom, atoms) of every k_sort_window workgroup
     uint32_t window_capacity;     // entries of `windows` = workgroups launched (the surplus exits)
     uint32_t *scan_block_sums;
     GridSums *grid_sums;   // per 256 structures: (cells, atoms) x (LDS-binned, tail), 4 x u64

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
         b.grids[s].sorted_base = in_lds ? (uint32_t)as : (uint32_t)(b.status->tail_atom_base + base.atoms_l + v.atoms_l - na);
         if (in_lds && !batch_aborted(b.status)) {
             const uint32_t w0 = (uint32_t)(as >> 32);
-            for (uint32_t w = 0; w < n_win; w++) b.windows[w0 + w] = make_uint2(s, w);
+            for (uint32_t w = 0; w < n_win; w++) b.windows[w0 + w] = make_uint4(s, w, b.grids[s].atom_begin, na);
         }
     }
 }
@@ -279,102 +279,119 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
 // per-structure call, context.cpp run_small_host_batch).  They arrive as kernel arguments - no upload
 // precedes the launch, the inputs are read from pinned host memory - and the first workgroup stores
 // them where the later kernels look for them.
+constexpr uint32_t sort_window_threads(bool) { return 1024u; }
+#ifdef RSASA_SORT_PROF
+// throw-away build (tools/sort_prof.py): per-phase time of k_sort_window, 10 ns ticks summed over workgroups
+__device__ unsigned long long g_sort_prof[16];
+#define SORT_STAMP(k) do { if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); \
+    atomicAdd(&g_sort_prof[k], t_ - t_prev_); t_prev_ = t_; } } while (0)
+#else
+#define SORT_STAMP(k)
+#endif
 template <bool SINGLE>
-__global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView b, SingleJob single)
+__global__ __launch_bounds__(sort_window_threads(SINGLE), SINGLE ? 4 : 8) void k_sort_window(BatchView b, SingleJob single)
 {
-    constexpr int kSlots = 8;                              // atoms per thread with (cell, position) in registers
-    constexpr int kChunk = 4;                              // slots whose loads are in flight together
+    constexpr uint32_t kThreads = sort_window_threads(SINGLE);
+#ifdef RSASA_SORT_PROF
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memrealtime();
+#endif
+    constexpr int kSlots = 8192 / kThreads;                // atoms per thread with position and coordinates in registers
     constexpr uint32_t kStage = kWindowCells * 2u / 32u;   // 32-byte records the counter memory stages
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindowCells / 2 + 4];
+    constexpr uint32_t kPer = ((kWindowCells / 2u + kThreads - 1u) / kThreads) | 1u;  // counter words a thread scans (odd: no bank conflicts)
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindowCells / 2 + 4 + kPer + 3];
     __shared__ uint32_t smem32[16];
     __shared__ uint32_t s_below;
-    uint32_t s, c0;
+    // A workgroup's time is a chain of memory round trips (two workgroups per CU do not hide them), so the chain is
+    // kept short: the work-list entry carries the structure's atom range and is fetched beside the status words, and
+    // the coordinates of all slots are requested before the grid parameters have arrived.
+    uint32_t s, c0, a0, n_at;
     StructGrid g;
     if (SINGLE) {
         s = 0;
         c0 = blockIdx.x * kWindowCells;  // (one workgroup per window was launched)
         g = single.grid;
+        a0 = g.atom_begin; n_at = g.n_atoms;
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             b.grids[0] = g;
             *b.status = single.status;
         }
     } else {
+        const uint4 job = b.windows[blockIdx.x];  // (the launch covers the list's capacity: in bounds, maybe stale)
         if (batch_aborted(b.status) || blockIdx.x >= b.status->n_windows) return;
-        const uint2 job = b.windows[blockIdx.x];
         s = job.x;
         c0 = job.y * kWindowCells;
-        g = b.grids[s];
+        a0 = job.z; n_at = job.w;
     }
     const uint32_t tid = threadIdx.x;
-    const uint32_t a0 = g.atom_begin, a1 = g.atom_begin + g.n_atoms;
+    const uint32_t a1 = a0 + n_at;
     const float *__restrict__ px = b.x, *__restrict__ py = b.y, *__restrict__ pz = b.z;
     auto pr = [&](uint32_t i) { return load_radius(b.radius, b.radius8, b.radius_table, i); };
     const uint32_t *__restrict__ pid32 = b.id32;
     const uint64_t *__restrict__ pid = pid32 ? reinterpret_cast<const uint64_t *>(pid32) : b.id;  // (non-null: the batch has ids)
     uint32_t *__restrict__ rank_of = b.rank_of;  // sorted position of the atoms without a slot
-    const uint32_t dim_xy = g.dim_x * g.dim_y;
     uint4 *stage = reinterpret_cast<uint4 *>(s_cnt);
-    const uint32_t n_cells = min(kWindowCells, g.n_cells - c0), n_words = (n_cells + 1u) >> 1;
-    const bool last_window = c0 + n_cells == g.n_cells;
-
-    for (uint32_t i = tid; i < (n_words + 1u + 3u) / 4u; i += 1024u) stage[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) s_below = 0;
-    // ---- cells of the structure's first kSlots * 1024 atoms (slot k of a thread: atom a0 + tid + 1024 k) ----
-    uint32_t rcell[kSlots], rpos[kSlots];
+    // ---- the structure's first kSlots * 1024 atoms (slot k of a thread: atom a0 + tid + 1024 k) ----
+    float x[kSlots], y[kSlots], z[kSlots];
     // SINGLE: the whole record stays in registers (the inputs sit in host memory there: one trip over
     // the link instead of two; a workgroup has the CU to itself and 128 VGPRs)
-    float kx[SINGLE ? kSlots : 1], ky[SINGLE ? kSlots : 1], kz[SINGLE ? kSlots : 1], kr[SINGLE ? kSlots : 1];
+    float kr[SINGLE ? kSlots : 1];
     uint64_t kid[SINGLE ? kSlots : 1];
-    uint32_t below = 0;  // atoms in earlier windows (wave-uniform count)
 #pragma unroll
-    for (int k0 = 0; k0 < kSlots; k0 += kChunk) {
-        float x[kChunk], y[kChunk], z[kChunk];
-#pragma unroll
-        for (int k = 0; k < kChunk; k++) {
-            x[k] = y[k] = z[k] = 0.f;
-            if (SINGLE) { kr[k0 + k] = 0.f; kid[k0 + k] = 0ull; }
-            if (1024u * (k0 + k) < g.n_atoms) {
-                const uint32_t i = min(a0 + tid + 1024u * (k0 + k), a1 - 1u);
-                x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
-                if (SINGLE) {
-                    kr[k0 + k] = pr(i);
-                    if (pid) kid[k0 + k] = load_id(b.id, pid32, i);
-                }
+    for (int k = 0; k < kSlots; k++) {
+        x[k] = y[k] = z[k] = 0.f;
+        if (SINGLE) { kr[k] = 0.f; kid[k] = 0ull; }
+        if (kThreads * k < n_at) {
+            const uint32_t i = min(a0 + tid + kThreads * k, a1 - 1u);
+            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+            if (SINGLE) {
+                kr[k] = pr(i);
+                if (pid) kid[k] = load_id(b.id, pid32, i);
             }
-            if (SINGLE) { kx[k0 + k] = x[k]; ky[k0 + k] = y[k]; kz[k0 + k] = z[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < kChunk; k++) {
-            uint32_t cx, cy, cz;
-            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
-            const bool live = a0 + tid + 1024u * (k0 + k) < a1;
-            const uint32_t c = cx + cy * g.dim_x + cz * dim_xy;
-            // cell relative to the window; no atom in this slot or another window's: >= n_cells
-            rcell[k0 + k] = live ? c - c0 : 0xFFFFFFFFu;
-            rpos[k0 + k] = 0;
-            if (c0) below += (uint32_t)__popcll(ballot64(live && c < c0));
         }
     }
-    const uint32_t a_rest = a0 + 1024u * kSlots;  // first atom without a slot
+    if (!SINGLE) g = b.grids[s];
+    const uint32_t dim_xy = g.dim_x * g.dim_y;
+    const uint32_t n_cells = min(kWindowCells, g.n_cells - c0), n_words = (n_cells + 1u) >> 1;
+    const bool last_window = c0 + n_cells == g.n_cells;
+    // (counters, the end marker's word, and - for the scan's whole runs - up to a multiple of kPer words)
+    for (uint32_t i = tid; i < ((n_words / kPer + 1u) * kPer + 3u) / 4u; i += kThreads) stage[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) s_below = 0;
+    // cell relative to the window; no atom in this slot or another window's: >= n_cells.  Once the positions are
+    // known, rpos alone says whether the slot is this window's (kNotMine).
+    constexpr uint32_t kNotMine = 0xFFFFFFFFu;
+    uint32_t rcell[kSlots], rpos[kSlots];
+    uint32_t below = 0;  // atoms in earlier windows (wave-uniform count)
+#pragma unroll
+    for (int k = 0; k < kSlots; k++) {
+        uint32_t cx, cy, cz;
+        cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+        const bool live = a0 + tid + kThreads * k < a1;
+        const uint32_t c = cx + cy * g.dim_x + cz * dim_xy;
+        rcell[k] = live ? c - c0 : 0xFFFFFFFFu;
+        rpos[k] = kNotMine;
+        if (c0) below += (uint32_t)__popcll(ballot64(live && c < c0));
+    }
+    const uint32_t a_rest = a0 + kThreads * kSlots;  // first atom without a slot
     __syncthreads();
+    SORT_STAMP(0);
     // ---- count (spatial_grid.rs:53-62) ----
 #pragma unroll
     for (int k = 0; k < kSlots; k++) {
         const uint32_t lc = rcell[k];
         if (lc < n_cells) atomicAdd(&s_cnt[lc >> 1], 1u << ((lc & 1u) * 16u));
     }
-    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4096u) {  // four atoms per trip, loads first
-        float x[4], y[4], z[4];
+    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4u * kThreads) {  // four atoms per trip, loads first
+        float xx[4], yy[4], zz[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
-            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+            const uint32_t i = min(i0 + kThreads * k, a1 - 1u);
+            xx[k] = px[i]; yy[k] = py[i]; zz[k] = pz[i];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             uint32_t cx, cy, cz;
-            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
-            const bool live = i0 + 1024u * k < a1;
+            cell_coords(g, xx[k], yy[k], zz[k], cx, cy, cz);
+            const bool live = i0 + kThreads * k < a1;
             const uint32_t c = cx + cy * g.dim_x + cz * dim_xy, lc = c - c0;
             if (live && lc < n_cells) atomicAdd(&s_cnt[lc >> 1], 1u << ((lc & 1u) * 16u));
             if (c0) below += (uint32_t)__popcll(ballot64(live && c < c0));
@@ -382,59 +399,88 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
     }
     if (c0 && lane_id() == 0 && below) atomicAdd(&s_below, below);
     __syncthreads();
-    // ---- exclusive scan (spatial_grid.rs:65-68): every thread owns an odd number of consecutive
-    // words (odd stride: no bank conflicts), sums them, the partial sums are scanned across the
-    // workgroup, and the words are rewritten as (start of the even cell | start of the odd one << 16),
-    // counted from the structure's first sorted atom: < 65536, it has < 65536 atoms
+    SORT_STAMP(1);
+    // ---- exclusive scan (spatial_grid.rs:65-68): every thread owns kPer consecutive words (odd stride: no
+    // bank conflicts), fetched in one go, sums them, the partial sums are scanned across the workgroup, and the
+    // words are rewritten as (start of the even cell | start of the odd one << 16), counted from the
+    // structure's first sorted atom: < 65536, it has < 65536 atoms
     const uint32_t placed = s_below;  // the window's first position
-    const uint32_t per = ((n_words + 1023u) / 1024u) | 1u;
-    const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
-    uint32_t sum = 0;
-    for (uint32_t j = w0; j < w1; j++) {
-        const uint32_t v = s_cnt[j];
-        sum += (v & 0xFFFFu) + (v >> 16);
-    }
     uint32_t total;
-    uint32_t running = placed + block_incl_scan<16>(sum, smem32, total) - sum;
-    for (uint32_t j = w0; j < w1; j++) {
-        const uint32_t v = s_cnt[j];
-        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
-        s_cnt[j] = running | ((running + lo) << 16);
-        running += lo + hi;
+    if constexpr (SINGLE) {  // (keeps its registers for the records)
+        const uint32_t per = ((n_words + kThreads - 1u) / kThreads) | 1u;
+        const uint32_t w0 = min(tid * per, n_words), w1 = min(w0 + per, n_words);
+        uint32_t sum = 0;
+        for (uint32_t j = w0; j < w1; j++) {
+            const uint32_t v = s_cnt[j];
+            sum += (v & 0xFFFFu) + (v >> 16);
+        }
+        uint32_t running = placed + block_incl_scan<kThreads / kWave>(sum, smem32, total) - sum;
+        for (uint32_t j = w0; j < w1; j++) {
+            const uint32_t v = s_cnt[j];
+            const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+            s_cnt[j] = running | ((running + lo) << 16);
+            running += lo + hi;
+        }
+    } else {
+        // (whole runs only: the counters were zeroed up to a multiple of kPer words past the end marker's word, and
+        // a zero counter behind the last cell takes the window's end as its start - which is what the marker is)
+        const uint32_t w0 = tid * kPer;
+        const bool mine = w0 <= n_words;
+        uint32_t *own = s_cnt + (mine ? w0 : 0u);
+        uint32_t cv[kPer];
+        uint32_t sum = 0;
+        if (mine) {
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) cv[j] = own[j];
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) sum += (cv[j] & 0xFFFFu) + (cv[j] >> 16);
+        }
+        uint32_t running = placed + block_incl_scan<kThreads / kWave>(sum, smem32, total) - sum;
+        if (mine) {
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; j++) {
+                const uint32_t lo = cv[j] & 0xFFFFu, hi = cv[j] >> 16;
+                own[j] = running | ((running + lo) << 16);
+                running += lo + hi;
+            }
+        }
     }
     // the end marker the last cell's run length is read from: with an odd number of cells it is
     // the upper half of the last word already (an empty cell's start), else the word after
-    if (last_window && tid == 0 && (n_cells & 1u) == 0u) s_cnt[n_words] = g.n_atoms;
+    if (SINGLE && last_window && tid == 0 && (n_cells & 1u) == 0u) s_cnt[n_words] = g.n_atoms;
     __syncthreads();
+    SORT_STAMP(2);
     // ---- cell starts: the words as they are, eight cells per store ----
     {
         uint4 *out = reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(b.cells) + g.cell_base + c0);
         const uint32_t n16 = n_cells + (last_window ? 1u : 0u);
-        for (uint32_t i = tid; i < (n16 + 7u) / 8u; i += 1024u) out[i] = stage[i];
+        for (uint32_t i = tid; i < (n16 + 7u) / 8u; i += kThreads) out[i] = stage[i];
     }
     __syncthreads();  // the starts turn into the cells' cursors
+    SORT_STAMP(3);
     // ---- positions (spatial_grid.rs:70-93): an atom takes the next free position of its cell.
     // The order inside a cell is the order of arrival - the results do not depend on it.
 #pragma unroll
     for (int k = 0; k < kSlots; k++) {
+        if (!SINGLE) asm volatile("" : "+v"(rcell[k]));  // (word and shift are computed again, not kept from the count pass)
         const uint32_t lc = rcell[k];
         if (lc < n_cells) {
             const uint32_t sh = (lc & 1u) * 16u;
             rpos[k] = (atomicAdd(&s_cnt[lc >> 1], 1u << sh) >> sh) & 0xFFFFu;
         }
     }
-    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4096u) {  // atoms without a slot: position through memory
-        float x[4], y[4], z[4];
+    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4u * kThreads) {  // atoms without a slot: position through memory
+        float xx[4], yy[4], zz[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
-            x[k] = px[i]; y[k] = py[i]; z[k] = pz[i];
+            const uint32_t i = min(i0 + kThreads * k, a1 - 1u);
+            xx[k] = px[i]; yy[k] = py[i]; zz[k] = pz[i];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t i = i0 + 1024u * k;
+            const uint32_t i = i0 + kThreads * k;
             uint32_t cx, cy, cz;
-            cell_coords(g, x[k], y[k], z[k], cx, cy, cz);
+            cell_coords(g, xx[k], yy[k], zz[k], cx, cy, cz);
             const uint32_t lc = cx + cy * g.dim_x + cz * dim_xy - c0;
             if (i < a1 && lc < n_cells) {
                 const uint32_t sh = (lc & 1u) * 16u;
@@ -443,12 +489,16 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
         }
     }
     __syncthreads();  // the cursors are dead: their memory stages the records, by position
+    SORT_STAMP(4);
     const uint32_t out0 = g.sorted_base + placed;  // this window's atoms are [out0, out0 + total)
     const uint32_t n_staged = min(total, kStage);
     // 32 bytes per atom: (x, y, z, radius) and (input index, id fold, id)
+    constexpr int kChunk = 4;  // slots whose loads are in flight together (64 registers per wave)
+    uint32_t tid5 = tid;       // (an index the compiler cannot tie to the first pass: it would keep that pass's
+    asm volatile("" : "+v"(tid5));  // 64-bit addresses alive across the whole kernel, in scratch)
 #pragma unroll
     for (int k0 = 0; k0 < kSlots; k0 += kChunk) {
-        if (1024u * k0 < g.n_atoms) {
+        if (kThreads * k0 < n_at) {
             float4 v[kChunk];
             uint64_t id[kChunk];
 #pragma unroll
@@ -456,18 +506,18 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                 v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                 id[k] = 0ull;
                 if (SINGLE) {
-                    v[k] = make_float4(kx[k0 + k], ky[k0 + k], kz[k0 + k], kr[k0 + k]);
+                    v[k] = make_float4(x[k0 + k], y[k0 + k], z[k0 + k], kr[k0 + k]);
                     id[k] = kid[k0 + k];
-                } else if (rcell[k0 + k] < n_cells) {
-                    const uint32_t i = a0 + tid + 1024u * (k0 + k);
+                } else if (rpos[k0 + k] != kNotMine) {
+                    const uint32_t i = a0 + tid5 + kThreads * (k0 + k);
                     v[k] = make_float4(px[i], py[i], pz[i], pr(i));
                     if (pid) id[k] = load_id(b.id, pid32, i);
                 }
             }
 #pragma unroll
             for (int k = 0; k < kChunk; k++) {
-                const uint32_t rel = rpos[k0 + k] - placed, i = a0 + tid + 1024u * (k0 + k);
-                if (rcell[k0 + k] < n_cells) {
+                const uint32_t rel = rpos[k0 + k] - placed, i = a0 + tid5 + kThreads * (k0 + k);
+                if (rpos[k0 + k] != kNotMine) {
                     if (rel < kStage) {
                         stage[2u * rel] = __builtin_bit_cast(uint4, v[k]);
                         stage[2u * rel + 1u] = make_uint4(i, fold_id(id[k]), (uint32_t)id[k], (uint32_t)(id[k] >> 32));
@@ -481,20 +531,20 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
             }
         }
     }
-    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4096u) {
+    for (uint32_t i0 = a_rest + tid; i0 < a1; i0 += 4u * kThreads) {
         float4 v[4];
-        uint64_t id[4];
+        uint64_t idr[4];
         uint32_t pos[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t i = min(i0 + 1024u * k, a1 - 1u);
+            const uint32_t i = min(i0 + kThreads * k, a1 - 1u);
             pos[k] = rank_of[i];  // (another window's atom: not ours to read, ignored below)
             v[k] = make_float4(px[i], py[i], pz[i], pr(i));
-            id[k] = pid ? load_id(b.id, pid32, i) : 0ull;
+            idr[k] = pid ? load_id(b.id, pid32, i) : 0ull;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t i = i0 + 1024u * k;
+            const uint32_t i = i0 + kThreads * k;
             uint32_t cx, cy, cz;
             cell_coords(g, v[k].x, v[k].y, v[k].z, cx, cy, cz);
             const uint32_t lc = cx + cy * g.dim_x + cz * dim_xy - c0;
@@ -502,18 +552,19 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
                 const uint32_t rel = pos[k] - placed;
                 if (rel < kStage) {
                     stage[2u * rel] = __builtin_bit_cast(uint4, v[k]);
-                    stage[2u * rel + 1u] = make_uint4(i, fold_id(id[k]), (uint32_t)id[k], (uint32_t)(id[k] >> 32));
+                    stage[2u * rel + 1u] = make_uint4(i, fold_id(idr[k]), (uint32_t)idr[k], (uint32_t)(idr[k] >> 32));
                 } else {
                     const uint32_t p = g.sorted_base + pos[k];
                     b.sorted_xyzr[p] = v[k];
                     b.sorted_orig[p] = i;
-                    if (pid) { if (b.sorted_id) b.sorted_id[p] = id[k]; b.sorted_id32[p] = fold_id(id[k]); }
+                    if (pid) { if (b.sorted_id) b.sorted_id[p] = idr[k]; b.sorted_id32[p] = fold_id(idr[k]); }
                 }
             }
         }
     }
     __syncthreads();
-    for (uint32_t j = tid; j < n_staged; j += 1024u) {
+    SORT_STAMP(5);
+    for (uint32_t j = tid; j < n_staged; j += kThreads) {
         const uint4 q = stage[2u * j + 1u];
         b.sorted_xyzr[out0 + j] = __builtin_bit_cast(float4, stage[2u * j]);
         b.sorted_orig[out0 + j] = q.x;
@@ -522,8 +573,22 @@ __global__ __launch_bounds__(1024, SINGLE ? 4 : 8) void k_sort_window(BatchView 
             if (b.sorted_id) b.sorted_id[out0 + j] = (uint64_t)q.z | ((uint64_t)q.w << 32);
         }
     }
-    for (uint32_t j = tid; j < total; j += 1024u) b.sid_sorted[out0 + j] = s;
+    for (uint32_t j = tid; j < total; j += kThreads) b.sid_sorted[out0 + j] = s;
+#ifdef RSASA_SORT_PROF
+    __syncthreads();
+    SORT_STAMP(6);
+    if (threadIdx.x == 0) { atomicAdd(&g_sort_prof[8], 1ull); atomicAdd(&g_sort_prof[9], (unsigned long long)n_cells);
+                            atomicAdd(&g_sort_prof[10], (unsigned long long)total); atomicAdd(&g_sort_prof[11], (unsigned long long)g.n_atoms); }
+#endif
 }
+#ifdef RSASA_SORT_PROF
+extern "C" __attribute__((visibility("default"))) int rsasa_debug_sort_prof(unsigned long long *out)
+{
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_prof), sizeof(zero)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_sort_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif
 
 // ---- batch-wide path for the structures of the tail (cells do not fit the LDS) ----
 
@@ -678,14 +743,14 @@ void launch_grid_prepare(const BatchView &b, hipStream_t stream)
 // the surplus exits.
 void launch_sort_lds(const BatchView &b, hipStream_t stream)
 {
-    if (b.window_capacity) hipLaunchKernelGGL(k_sort_window<false>, dim3(b.window_capacity), dim3(1024), 0, stream, b, SingleJob{});
+    if (b.window_capacity) hipLaunchKernelGGL(k_sort_window<false>, dim3(b.window_capacity), dim3(sort_window_threads(false)), 0, stream, b, SingleJob{});
 }
 
 // One structure, grid and status from the host (see k_sort_window<true>): one workgroup per window.
 void launch_sort_single(const BatchView &b, const SingleJob &job, hipStream_t stream)
 {
     const uint32_t n_win = grid_windows(job.grid.n_cells);
-    if (n_win) hipLaunchKernelGGL(k_sort_window<true>, dim3(n_win), dim3(1024), 0, stream, b, job);
+    if (n_win) hipLaunchKernelGGL(k_sort_window<true>, dim3(n_win), dim3(sort_window_threads(true)), 0, stream, b, job);
 }
 
 // Batch-wide binning of the other structures (the tail).  Independent of launch_sort_lds: the

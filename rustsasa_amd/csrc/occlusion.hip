@@ -81,7 +81,11 @@ void launch_fast2(bool half1, uint32_t n_blocks, hipStream_t stream, const OccAr
 template <int NT, bool MULTI, int NW>
 void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
 {
-    const uint32_t n_blocks = cdiv(n_atoms, NW * a3.atoms_per_wave);
+    // persistent waves (occlusion_mx.inc): as many workgroups as the GPU holds at once - 28 waves per CU at 72
+    // registers, 24 at 80 (NW >= 8) - or fewer when the batch has fewer blocks of atoms_per_wave atoms than that
+    const uint32_t resident = 256u * (NW == 4 ? 7u : NW == 8 ? 3u : 2u);
+    const uint32_t n_blocks = mx_persistent(MULTI) ? min(cdiv(n_atoms, NW * a3.atoms_per_wave), resident) : cdiv(n_atoms, NW * a3.atoms_per_wave);
+    if (mx_persistent(MULTI)) (void)hipMemsetAsync(a3.claim, 0, 8u * kClaimStride * 4u, stream);  // (a failure shows as the launch's)
     if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
     else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
     else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
@@ -157,6 +161,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         const bool rem = lat.n_points != lat.n_fused;
         const bool half1 = lat.n_fused <= 96u;  // the second chunk's fused points fit half a wave
         a3.part = part;
+        a3.claim = b.claim + (part == kOccRest ? 8u * kClaimStride : 0u);
         if (mx) {
             // group-union sweep + matrix-core point tests: 64 atoms per wave
             // 64 atoms per wave once that still leaves about four rounds of waves (256 CUs x 4 SIMDs x 7

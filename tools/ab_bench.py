@@ -36,10 +36,13 @@ def main():
                 print(name, "FAILED", p.stderr[-400:])
                 continue
             d = json.loads(p.stdout.strip().split("\n")[-1])
-            res[name].append((d["kernel_ms"]["occlusion"], d["ms_per_step"], d["kernel_ms"]["grid_build"]))
+            one = d.get("one_at_a_time") or {}
+            res[name].append((d["kernel_ms"]["occlusion"], d["ms_per_step"], d["kernel_ms"]["grid_build"],
+                              one.get("grid_build_kernel_ms", float("nan")), one.get("ms_per_step", float("nan"))))
     for name, v in res.items():
         if v:
-            print(f"{name:24s} occlusion ms min {min(x[0] for x in v):.4f}  all {[round(x[0], 3) for x in v]}  step ms min {min(x[1] for x in v):.4f}  grid ms min {min(x[2] for x in v):.4f}")
+            print(f"{name:24s} occlusion ms min {min(x[0] for x in v):.4f}  all {[round(x[0], 3) for x in v]}  step ms min {min(x[1] for x in v):.4f}  grid ms min {min(x[2] for x in v):.4f}"
+                  f"  alone: grid ms min {min(x[3] for x in v):.4f} step ms min {min(x[4] for x in v):.4f}")
 
 
 if __name__ == "__main__":
