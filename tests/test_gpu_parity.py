@@ -477,6 +477,24 @@ def test_matrix_core_kernel_hands_over_what_it_does_not_take(monkeypatch):
             assert np.array_equal(got, want), (probe, scale, int(np.sum(got != want)))
 
 
+def test_matrix_core_kernel_and_grids_wider_than_1024_cells(monkeypatch):
+    """k_occlusion_mx keeps an atom's three cell coordinates in one register, ten bits each; a structure whose grid has
+    more than 1024 cells along an axis is left to the general kernel.  Stretched copies of ordinary structures - two
+    compact halves 4 000 A apart along x, y or z - among ordinary ones, all equal to the oracle."""
+    import rustsasa_amd
+    monkeypatch.setenv("RSASA_OCCLUSION_KERNEL", "5")
+    b = bw.synthetic_proteome(6, seed=9)
+    so = b.structure_offsets
+    x, y, z = b.x.copy(), b.y.copy(), b.z.copy()
+    for s, axis in ((1, x), (3, y), (4, z)):
+        half = (so[s] + so[s + 1]) // 2
+        axis[half:so[s + 1]] += np.float32(4000.0)  # > 1024 cells of probe + max_r (about 3.3 A) between the halves
+    with rustsasa_amd.Context(0) as c:
+        got, _ = c.calculate_sasa_batch(x, y, z, b.radius, b.ids, so, PROBE, 100)
+    want = po.calculate_sasa_batch(x, y, z, b.radius, b.ids, so, PROBE, 100, 8, threads=4)
+    assert np.array_equal(got, want), int(np.sum(got != want))
+
+
 def test_default_dispatch_at_the_matrix_core_threshold(ctx):
     """Batches of 32 768 atoms or more take k_occlusion_mx, smaller ones the per-atom kernels: both sides of the
     boundary, default settings, against the oracle."""
