@@ -898,6 +898,14 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
         for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid[w], hipEventDisableTiming);
     } else if (e == hipSuccess) {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        // Experiment (RSASA_GRID_PRIO=1): the grid builds on a stream of the highest priority, so that their workgroups -
+        // shaped to fit the slot an occlusion workgroup leaves - are dispatched ahead of the other batch's
+        if (e == hipSuccess && std::getenv("RSASA_GRID_PRIO")) {
+            int least = 0, greatest = 0;
+            e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->grid_stream, hipStreamNonBlocking, greatest);
+            for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid[w], hipEventDisableTiming);
+        }
     }
     for (int w = 0; w < rsasa_context::kInFlight; w++) {
         for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ws[w].ev[i]);

@@ -171,7 +171,13 @@ void launch_expand_frames(const float *xyz, const float *radius, const uint64_t 
 
 constexpr uint32_t kSegmentAtoms = 4096;  // atoms per bounds workgroup
 constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
-constexpr uint32_t kWindowCells = 36864;  // cells one k_sort_window workgroup bins (16-bit counters, 72 KiB: two per CU)
+#ifndef RSASA_WINDOW_CELLS
+#define RSASA_WINDOW_CELLS 36864
+#endif
+#ifndef RSASA_SORT_THREADS
+#define RSASA_SORT_THREADS 1024
+#endif
+constexpr uint32_t kWindowCells = RSASA_WINDOW_CELLS;  // cells one k_sort_window workgroup bins (16-bit counters, 72 KiB: two per CU)
 constexpr uint32_t kLdsMaxAtoms = 65536;  // structures with fewer atoms are binned in LDS (16-bit positions)
 
 // 16-bit entries a structure of n_cells cells takes in the cell array: its cells, the end marker,

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_grid_bases(BatchView b)
 // per-structure call, context.cpp run_small_host_batch).  They arrive as kernel arguments - no upload
 // precedes the launch, the inputs are read from pinned host memory - and the first workgroup stores
 // them where the later kernels look for them.
-constexpr uint32_t sort_window_threads(bool) { return 1024u; }
+constexpr uint32_t sort_window_threads(bool single) { return single ? 1024u : (uint32_t)RSASA_SORT_THREADS; }
 #ifdef RSASA_SORT_PROF
 // throw-away build (tools/sort_prof.py): per-phase time of k_sort_window, 10 ns ticks summed over workgroups
 __device__ unsigned long long g_sort_prof[16];
@@ -289,13 +289,13 @@ __device__ unsigned long long g_sort_prof[16];
 #define SORT_STAMP(k)
 #endif
 template <bool SINGLE>
-__global__ __launch_bounds__(sort_window_threads(SINGLE), SINGLE ? 4 : 8) void k_sort_window(BatchView b, SingleJob single)
+__global__ __launch_bounds__(sort_window_threads(SINGLE), SINGLE ? 4 : (RSASA_SORT_THREADS == 1024 ? 8 : 7)) void k_sort_window(BatchView b, SingleJob single)
 {
     constexpr uint32_t kThreads = sort_window_threads(SINGLE);
 #ifdef RSASA_SORT_PROF
     unsigned long long t_prev_ = __builtin_amdgcn_s_memrealtime();
 #endif
-    constexpr int kSlots = 8192 / kThreads;                // atoms per thread with position and coordinates in registers
+    constexpr int kSlots = 8;                              // atoms per thread with position and coordinates in registers
     constexpr uint32_t kStage = kWindowCells * 2u / 32u;   // 32-byte records the counter memory stages
     constexpr uint32_t kPer = ((kWindowCells / 2u + kThreads - 1u) / kThreads) | 1u;  // counter words a thread scans (odd: no bank conflicts)
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[kWindowCells / 2 + 4 + kPer + 3];

@@ -55,6 +55,17 @@ __global__ __launch_bounds__(256) void k(int iters, Stamp *out, float *sink)
             if (MODE == 9)
                 for (int f = 0; f < FILL; f += 4)
                     asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %0\n v_pk_add_f32 %0, %0, %1" : "+v"(pa), "+v"(pb), "+v"(pc));
+            // MODE 10 / 11: the same addition in its 4-byte (VOP2) and 8-byte (VOP3) encoding; MODE 12: 4-byte with a 32-bit
+            // literal behind it (8 bytes): is an instruction's cost its issue slot, or the bytes the CU has to fetch?
+            if (MODE == 10)
+                for (int f = 0; f < FILL; f += 4)
+                    asm volatile("v_add_f32_e32 %0, %0, %1\n v_add_f32_e32 %1, %1, %2\n v_add_f32_e32 %2, %2, %0\n v_add_f32_e32 %3, %3, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+            if (MODE == 11)
+                for (int f = 0; f < FILL; f += 4)
+                    asm volatile("v_add_f32_e64 %0, %0, %1\n v_add_f32_e64 %1, %1, %2\n v_add_f32_e64 %2, %2, %0\n v_add_f32_e64 %3, %3, %1" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
+            if (MODE == 12)
+                for (int f = 0; f < FILL; f += 4)
+                    asm volatile("v_add_f32_e32 %0, 0x3f8ccccd, %0\n v_add_f32_e32 %1, 0x3f8ccccd, %1\n v_add_f32_e32 %2, 0x3f8ccccd, %2\n v_add_f32_e32 %3, 0x3f8ccccd, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(e));
             if (MODE == 3)
                 for (int f = 0; f < FILL; f += 4)
                     asm volatile("s_add_u32 %0, %0, %1\n s_xor_b32 %1, %1, %0\n s_add_u32 %0, %0, %1\n s_xor_b32 %1, %1, %0" : "+s"(s0), "+s"(s1) :: "scc");
@@ -103,6 +114,9 @@ int main()
     (void)hipMalloc(&d, sizeof(Stamp) * 256 * 8 * 4);
     (void)hipMalloc(&sink, 64);
     const int ws[] = {1, 2, 4, 7, 8};
+    for (int w : ws) run<10, 16>("v_add_f32 (4 bytes) x16", w, d, sink);
+    for (int w : ws) run<11, 16>("v_add_f32 (8 bytes, VOP3) x16", w, d, sink);
+    for (int w : ws) run<12, 16>("v_add_f32 + literal (8 bytes) x16", w, d, sink);
     for (int w : ws) run<0, 16>("v_fma_f32 x16", w, d, sink);
     for (int w : ws) run<9, 16>("v_pk_mul/add_f32 x16", w, d, sink);
     for (int w : ws) run<3, 16>("s_add/s_xor x16", w, d, sink);
