@@ -1184,6 +1184,148 @@ bool fast_pdb_prepare(const std::string &text, const OptionValues &o, SegKind ki
     return true;
 }
 
+
+// The same short cut for mmCIF text (AlphaFold's files: one `_atom_site` loop, a row per line, no alternate locations):
+// the rows' tokens are looked at in place, the kept atoms written as prepare<Level> would have written them, and the
+// model keeps chains, residues and one named conformer each.  The exits are the PDB short cut's: an alternate location,
+// a chain or residue that comes back or goes down, a second name inside a residue, a row that is not exactly the
+// header's columns, a missing element or radius, a second `_atom_site` loop - the general reader takes the file.
+bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind kind, Structure &light, Prepared &p)
+{
+    if (o.radii_config) return false;
+    const ProtorFlat &protor = protor_flat();
+    std::pmr::memory_resource *const mem = light.chains.get_allocator().resource();
+    p.atoms.clear();
+    p.seg_end.clear();
+    p.atoms.reserve(text.size() / 96 + 1);
+    std::vector<std::string> cols;
+    static thread_local std::vector<TextView> tok;
+    bool in_loop = false, in_atom_site = false, resolved = false, had_rows = false;
+    std::string first_model;
+    int c_group = -1, c_id = -1, c_sym = -1, c_atom = -1, c_alt = -1, c_comp = -1, c_lasym = -1, c_aasym = -1, c_lseq = -1,
+        c_aseq = -1, c_ins = -1, c_x = -1, c_y = -1, c_z = -1, c_occ = -1, c_model = -1;
+    auto col = [&](const char *name) -> int {
+        for (size_t i = 0; i < cols.size(); i++)
+            if (cols[i] == name) return (int)i;
+        return -1;
+    };
+    auto val = [&](int c) -> TextView {  // "." and "?" stand for no value
+        if (c < 0) return {"", 0};
+        const TextView &t = tok[(size_t)c];
+        return (t.second == 1 && (t.first[0] == '.' || t.first[0] == '?')) ? TextView{t.first, 0} : t;
+    };
+    bool have_res = false;
+    std::int64_t res_seq = 0;
+    const char *cur = text.data(), *const end = text.data() + text.size();
+    while (cur < end) {
+        const LineView raw = next_line(cur, end);
+        const TextView tv = field_view(raw, 1, raw.n);  // trimmed
+        if (tv.second == 0) continue;
+        const LineView t{tv.first, tv.second};
+        if (t.n == 5 && t.starts_with("loop_")) { in_loop = true; in_atom_site = false; cols.clear(); resolved = false; continue; }
+        if (t[0] == '#') { in_loop = false; in_atom_site = false; continue; }
+        if (in_loop && t[0] == '_') {
+            if (t.starts_with("_atom_site.")) {
+                if (had_rows) return false;  // a second loop of atoms
+                in_atom_site = true;
+                std::string name(t.p + 11, t.n - 11);
+                name = trim(name.substr(0, name.find_first_of(" \t")));
+                cols.push_back(name);
+            } else {
+                in_atom_site = false;
+            }
+            continue;
+        }
+        if (!(in_loop && in_atom_site)) continue;
+        if (t[0] == '_') { in_loop = false; continue; }
+        if (!resolved) {
+            c_group = col("group_PDB"); c_id = col("id"); c_sym = col("type_symbol");
+            c_atom = col("label_atom_id"); c_alt = col("label_alt_id"); c_comp = col("label_comp_id");
+            c_lasym = col("label_asym_id"); c_aasym = col("auth_asym_id"); c_lseq = col("label_seq_id");
+            c_aseq = col("auth_seq_id"); c_ins = col("pdbx_PDB_ins_code"); c_x = col("Cartn_x");
+            c_y = col("Cartn_y"); c_z = col("Cartn_z"); c_occ = col("occupancy"); c_model = col("pdbx_PDB_model_num");
+            resolved = true;
+            if (c_x < 0 || c_y < 0 || c_z < 0 || c_atom < 0 || c_comp < 0) return false;  // (the general reader reports it)
+        }
+        tokenize_views(t, tok);
+        if (tok.size() != cols.size()) return false;
+        had_rows = true;
+        const TextView model_id = val(c_model);
+        if (first_model.empty()) first_model = model_id.second ? std::string(model_id.first, model_id.second) : "1";
+        if (model_id.second && !same(first_model, model_id)) continue;
+        if (val(c_alt).second) return false;
+        const TextView chain_id = c_aasym >= 0 && val(c_aasym).second ? val(c_aasym) : val(c_lasym);
+        const TextView seq_t = c_aseq >= 0 && val(c_aseq).second ? val(c_aseq) : val(c_lseq);
+        const std::int64_t seq = token_long(seq_t);
+        const TextView icode = val(c_ins), comp = val(c_comp), name = val(c_atom), group = val(c_group);
+        const bool same_chain = !light.chains.empty() && same(light.chains.back().id, chain_id);
+        bool same_res = false;
+        if (same_chain && have_res) {
+            const Residue &prev = light.chains.back().residues.back();
+            same_res = seq == res_seq && same(prev.insertion_code, icode);
+            if (same_res && !same(prev.conformers.front().name, comp)) return false;  // a second conformer
+        }
+        if (!same_res) {
+            if (same_chain) {
+                const Residue &prev = light.chains.back().residues.back();
+                const int c = prev.insertion_code.compare(0, std::string::npos, icode.first, icode.second);
+                if (!(seq > res_seq || (seq == res_seq && c < 0))) return false;
+            } else {
+                for (const Chain &ch : light.chains)
+                    if (same(ch.id, chain_id)) return false;
+                if (kind == SegKind::Chain && !light.chains.empty()) p.seg_end.push_back((uint32_t)p.atoms.size());
+                light.chains.push_back(Chain{std::string(chain_id.first, chain_id.second), std::pmr::vector<Residue>(mem)});
+            }
+            if (kind == SegKind::Residue && have_res) p.seg_end.push_back((uint32_t)p.atoms.size());
+            Chain &chain = light.chains.back();
+            chain.residues.push_back(Residue{seq, std::string(icode.first, icode.second), std::pmr::vector<Conformer>(mem)});
+            chain.residues.back().conformers.push_back(
+                Conformer{std::string(comp.first, comp.second), std::string(), std::pmr::vector<AtomRecord>(mem)});
+            have_res = true;
+            res_seq = seq;
+        }
+        // element: the symbol in upper case, else the first letter of the name (set_element); hydrogen / HETATM filters
+        const TextView sym = val(c_sym);
+        char e0 = 0;
+        bool one_letter = true;
+        if (sym.second) {
+            e0 = (char)std::toupper((unsigned char)sym.first[0]);
+            one_letter = sym.second == 1;
+        } else {
+            for (size_t k = 0; k < name.second && !e0; k++)
+                if (std::isalpha((unsigned char)name.first[k])) e0 = (char)std::toupper((unsigned char)name.first[k]);
+        }
+        if (!e0) return false;                                            // options.rs:164 (the general path reports it)
+        if (!o.include_hydrogens && e0 == 'H' && one_letter) continue;   // options.rs:166
+        const bool is_het = group.second == 6 && std::memcmp(group.first, "HETATM", 6) == 0;
+        if (is_het && !o.include_hetatms) continue;                      // options.rs:169
+        float radius = 0.f;
+        if (o.read_radii_from_occupancy) {
+            const TextView occ = val(c_occ);
+            radius = (float)(occ.second ? parse_decimal(occ.first, occ.second) : 1.0);  // options.rs:83-84
+        } else if (!protor.find(comp.first, comp.second, name.first, name.second, &radius)) {
+            if (!o.allow_vdw_fallback) return false;
+            std::string el = sym.second ? std::string(sym.first, sym.second) : std::string(1, e0);
+            for (auto &c : el) c = (char)std::toupper((unsigned char)c);
+            if (!vdw_radius(el, &radius)) return false;
+        }
+        auto num = [&](int c) {
+            const TextView v = val(c);
+            return v.second ? parse_decimal(v.first, v.second) : 0.0;
+        };
+        rsasa_atom_t a;
+        a.position[0] = (float)num(c_x);                                  // options.rs:106-110: f64 -> f32
+        a.position[1] = (float)num(c_y);
+        a.position[2] = (float)num(c_z);
+        a.radius = radius;
+        a.id = fnv_hash_altloc_serial(kNoAltLoc, (std::size_t)token_long(val(c_id)));
+        p.atoms.push_back(a);
+    }
+    if (kind == SegKind::Residue && have_res) p.seg_end.push_back((uint32_t)p.atoms.size());
+    if (kind == SegKind::Chain && !light.chains.empty()) p.seg_end.push_back((uint32_t)p.atoms.size());
+    return true;
+}
+
 }  // namespace
 
 // Test hook (sasa_host_cli prepare): what directory mode hands to the GPU for one file - kept atoms, segment ends - and
@@ -1196,9 +1338,9 @@ std::string debug_prepare_json(const std::string &path, const OptionValues &o, i
     Prepared p;
     bool used_fast = false;
     const SegKind kinds[] = {SegKind::None, SegKind::Residue, SegKind::Chain, SegKind::Residue};
-    if (fast && !is_mmcif_path(path)) {
+    if (fast) {
         Structure light(text.size() / 8 + 4096);
-        if (fast_pdb_prepare(text, o, kinds[level], light, p)) {
+        if (is_mmcif_path(path) ? fast_cif_prepare(text, o, kinds[level], light, p) : fast_pdb_prepare(text, o, kinds[level], light, p)) {
             model = std::move(light);
             used_fast = true;
         }
@@ -1646,9 +1788,10 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
             try {
                 const std::string &text = read_whole_file(paths[base + i]);
                 const bool cif = is_mmcif_path(paths[base + i]);
-                if (fast_reader && !cif) {  // plain PDB files: kept atoms straight from the text (fast_pdb_prepare)
+                if (fast_reader) {  // plain files: kept atoms straight from the text (fast_pdb_prepare / fast_cif_prepare)
                     Structure light(text.size() / 8 + 4096);
-                    if (fast_pdb_prepare(text, o, seg_kind_of<Level>::value, light, c->prep[i])) {
+                    if (cif ? fast_cif_prepare(text, o, seg_kind_of<Level>::value, light, c->prep[i])
+                            : fast_pdb_prepare(text, o, seg_kind_of<Level>::value, light, c->prep[i])) {
                         c->pdbs[i] = std::move(light);
                         return;
                     }

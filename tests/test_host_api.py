@@ -380,6 +380,91 @@ def test_directory_modes_short_cut_equals_the_general_reader(tmp_path):
     assert n_fast > 40 and n_cases - n_fast > 40, (n_fast, n_cases)  # both routes were exercised
 
 
+def _pdb_to_mmcif(pdb_path, quote_names=True):
+    """The ATOM / HETATM records of a PDB file as an AlphaFold-style mmCIF text (one `_atom_site` loop, a row per line,
+    the column order of tests/golden/data/example.cif).  Test input only: no attempt at a complete mmCIF file."""
+    cols = ["group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "auth_asym_id",
+            "label_entity_id", "label_seq_id", "auth_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy",
+            "B_iso_or_equiv", "pdbx_formal_charge", "pdbx_PDB_model_num"]
+    rows, model = [], 1
+    for l in open(pdb_path):
+        l = l.rstrip("\n")
+        if l.startswith("MODEL"):
+            model = int(l[10:14] or 1)
+        if not l.startswith(("ATOM  ", "HETATM")) or len(l) < 54:
+            continue
+        name = l[12:16].strip()
+        if quote_names and "'" in name:
+            name = '"%s"' % name
+        dot = lambda t: t.strip() or "."  # noqa: E731
+        rows.append(" ".join([l[:6].strip(), dot(l[6:11]), dot(l[76:78]), name or ".", dot(l[16:17]), dot(l[17:20]), dot(l[21:22]),
+                              dot(l[21:22]), "1", dot(l[22:26]), dot(l[22:26]), dot(l[26:27]), dot(l[30:38]), dot(l[38:46]),
+                              dot(l[46:54]), dot(l[54:60]), dot(l[60:66]), "?", str(model)]))
+    return "data_test\n#\nloop_\n" + "".join("_atom_site.%s\n" % c for c in cols) + "\n".join(rows) + "\n#\n"
+
+
+def test_directory_modes_mmcif_short_cut_equals_the_general_reader(tmp_path):
+    """The same for mmCIF text (host_api.cpp fast_cif_prepare): the reference's AlphaFold fixture, the PDB fixtures
+    rewritten as `_atom_site` loops, and mutants of them that hit the short cut's exits - an alternate location, a chain
+    that comes back, rows swapped, a row with a token too few or too many, no element symbol, an atom without a radius,
+    a second model, a residue number that goes back, a second name inside a residue, an insertion code, a serial number
+    that is not one, a HETATM inside a residue, '?' for a coordinate, an early residue repeated later, a second loop."""
+    rng = np.random.default_rng(11)
+    texts = {"example.cif": open(sio.data_path("example.cif")).read()}
+    for name in ["151L_H3.pdb", "bad_seqadv_1A06.pdb", "1jcd.pdb", "2drt.pdb", "freesasa/2gpi.pdb", "freesasa/4c1a.pdb"]:
+        texts[name] = _pdb_to_mmcif(sio.data_path(name))
+    option_sets = [(), ("--include-hetatms", "--allow-vdw-fallback"), ("--include-hydrogens", "--allow-vdw-fallback"),
+                   ("--read-radii-from-occupancy",)]
+    n_fast = n_cases = 0
+
+    def compare(path, label):
+        nonlocal n_fast, n_cases
+        for level in (0, 1, 2, 3):
+            for opts in option_sets:
+                a, b = _prepare_json(path, level, True, *opts), _prepare_json(path, level, False, *opts)
+                n_fast += a.pop("fast")
+                b.pop("fast")
+                n_cases += 1
+                assert a == b, (label, level, opts, len(a["atoms"]), len(b["atoms"]), a["error"], b["error"])
+
+    for name, text in texts.items():
+        base = tmp_path / (os.path.basename(name) + ".cif")
+        base.write_text(text)
+        compare(base, name)
+        lines = text.split("\n")
+        atom_idx = [i for i, l in enumerate(lines) if l.startswith(("ATOM ", "HETATM "))]
+        for kind in range(16):
+            mut = list(lines)
+            i = int(rng.choice(atom_idx[5:-5]))
+            f = mut[i].split()
+
+            def put(k, v, row=None):
+                g = list(f if row is None else row)
+                g[k] = v
+                return " ".join(g)
+            if kind == 0:   mut[i] = put(4, "A")                                        # an alternate location
+            elif kind == 1: mut[i] = put(7, "Z")                                        # a one-atom chain in the middle
+            elif kind == 2: mut[i], mut[i + 1] = mut[i + 1], mut[i]                     # two rows swapped
+            elif kind == 3: mut[i] = " ".join(f[:-1])                                   # a token too few
+            elif kind == 4: mut[i] = put(2, "?")                                        # no element symbol
+            elif kind == 5: mut[i] = put(3, "XX")                                       # an atom name without a radius
+            elif kind == 6: mut[i:] = [put(18, "2", l.split()) if l.startswith(("ATOM ", "HETATM ")) else l for l in mut[i:]]  # a second model
+            elif kind == 7: mut[i] = put(10, "1")                                       # a residue number that goes back
+            elif kind == 8: mut[i] = put(5, "GLY" if f[5] != "GLY" else "ALA")          # another name inside a residue
+            elif kind == 9: mut[i] = put(11, "B")                                       # an insertion code
+            elif kind == 10: mut[i] = put(1, "abc")                                     # a serial number that is not one
+            elif kind == 11: mut[i] = put(0, "HETATM")                                  # a HETATM inside a residue
+            elif kind == 12: mut[i] = put(12, "?")                                      # no x coordinate
+            elif kind == 13: mut = mut[:i] + mut[atom_idx[2]:atom_idx[8]] + mut[i:]     # an early residue repeated later
+            elif kind == 14: mut[i] = mut[i] + " extra"                                 # a token too many
+            elif kind == 15: mut = mut[:i] + ["#", "loop_", "_atom_site.Cartn_x", "_atom_site.Cartn_y", "_atom_site.Cartn_z",
+                                               "_atom_site.label_atom_id", "_atom_site.label_comp_id", "1.0 2.0 3.0 CA ALA"] + ["#"]  # rows cut short, a second loop
+            path = tmp_path / f"mut_{os.path.basename(name)}_{kind}.cif"
+            path.write_text("\n".join(mut))
+            compare(path, f"{name} mutant {kind}")
+    assert n_fast > 60 and n_cases - n_fast > 60, (n_fast, n_cases)  # both routes were exercised
+
+
 def test_fixed_column_decimals_equal_the_general_parser(tmp_path):
     """The PDB reader takes %8.3f / %6.2f fields through a fixed-layout fast path (integer / power of ten, as Clinger's
     exact case) and everything else through the general parser / strtod: both must give the double Python's float()

@@ -38,7 +38,14 @@ def load_domains():
     return doms
 
 
-def write_structure(path, n_target, rng, doms):
+CIF_HEAD = "data_synthetic\n#\nloop_\n" + "".join("_atom_site.%s\n" % c for c in (
+    "group_PDB", "id", "type_symbol", "label_atom_id", "label_alt_id", "label_comp_id", "label_asym_id", "auth_asym_id",
+    "label_entity_id", "label_seq_id", "auth_seq_id", "pdbx_PDB_ins_code", "Cartn_x", "Cartn_y", "Cartn_z", "occupancy",
+    "B_iso_or_equiv", "pdbx_formal_charge", "pdbx_PDB_model_num"))
+
+
+def write_structure(path, n_target, rng, doms, cif=False):
+    """cif: the same atoms as an AlphaFold-style mmCIF file (the `_atom_site` loop of tests/golden/data/example.cif)."""
     lines, n, serial, resno, slot = [], 0, 1, 1, 0
     while n < n_target:
         recs, xyz, starts = doms[rng.integers(len(doms))]
@@ -65,13 +72,17 @@ def write_structure(path, n_target, rng, doms):
             prev_key = key
             x, y, z = frag[k - a0]
             name = a.name if len(a.name) == 4 else " " + a.name
-            lines.append("ATOM  %5d %-4s %3s %1s%4d    %8.3f%8.3f%8.3f  1.00  0.00          %2s  " %
-                         (serial % 100000, name, a.resname, chain, resno % 10000, x, y, z, a.element))
+            if cif:
+                lines.append("ATOM %-5d %s %-4s . %s %s %s 1 %-4d %-4d . %-8.3f %-8.3f %-8.3f 1.0 %-9.5f 0 1" %
+                             (serial, a.element, a.name, a.resname, chain, chain, resno, resno, x, y, z, 50.0 + (resno % 40)))
+            else:
+                lines.append("ATOM  %5d %-4s %3s %1s%4d    %8.3f%8.3f%8.3f  1.00  0.00          %2s  " %
+                             (serial % 100000, name, a.resname, chain, resno % 10000, x, y, z, a.element))
             serial += 1
         resno += 1
         n += a1 - a0
     with open(path, "w") as f:
-        f.write("\n".join(lines) + "\nEND\n")
+        f.write(CIF_HEAD + "\n".join(lines) + "\n#\n" if cif else "\n".join(lines) + "\nEND\n")
     return n
 
 
@@ -85,6 +96,7 @@ def main():
     ap.add_argument("--workers", type=int, default=0, help="GPU worker contexts (0 = the default context)")
     ap.add_argument("--devices", type=int, default=1)
     ap.add_argument("--calls", type=int, default=3, help="process_files calls per process (the first includes HIP start-up)")
+    ap.add_argument("--format", choices=("pdb", "cif"), default="pdb", help="the files' format (cif: AlphaFold-style mmCIF)")
     args = ap.parse_args()
     d = args.dir or tempfile.mkdtemp(prefix="rsasa_files_")
     rng = np.random.default_rng(bw.PROTEOME_SEED)
@@ -93,8 +105,8 @@ def main():
     t0 = time.time()
     paths, atoms = [], 0
     for i, n_t in enumerate(sizes):
-        p = os.path.join(d, f"s{i:05d}.pdb")
-        atoms += write_structure(p, int(n_t), rng, doms)
+        p = os.path.join(d, f"s{i:05d}.{args.format}")
+        atoms += write_structure(p, int(n_t), rng, doms, cif=args.format == "cif")
         paths.append(p)
     lst = os.path.join(d, "files.txt")
     open(lst, "w").write("\n".join(paths) + "\n")
@@ -118,7 +130,7 @@ def main():
                  "files_per_s_later_calls": round(best["n_files"] / best["later_calls_s"], 1) if best["later_calls_s"] else None,
                  "note": "files_per_s: a fresh process's first call (HIP runtime start-up inside); later calls of the same process: files_per_s_later_calls",
                  "atoms_per_file": round(atoms / args.files, 1), "generation_s": round(gen_s, 1),
-                 "host_threads": args.threads or os.cpu_count(),
+                 "host_threads": args.threads or os.cpu_count(), "format": args.format,
                  "bytes_on_disk": sum(os.path.getsize(p) for p in paths)})
     print(json.dumps(best))
 

@@ -7,7 +7,7 @@
 #   pmc.txt                    PMC summaries of the occlusion kernel (separate passes, no tracing): instruction mix, waits,
 #                              matrix-pipe busy / co-execution cycles, GRBM_GUI_ACTIVE (clock), FETCH_SIZE, WRITE_SIZE, TCC hits
 #   pmc_uniform1m.txt          the same instruction-mix, matrix-pipe and GRBM_GUI_ACTIVE passes for the 1M-atom / 960-point dispatch
-#   bench_uniform1m.json, single_and_pcie.json, files_mode.json, files_mode_1500.json, bench_shard_of_8.json,
+#   bench_uniform1m.json, single_and_pcie.json, files_mode.json, files_mode_1500.json, files_mode_cif.json, bench_shard_of_8.json,
 #   two_in_flight.txt, bench_run2.json (a second default run at the end)
 tag=${1:-round}
 out=gpurun_out/$tag
@@ -35,6 +35,7 @@ python3 bench.py --workload uniform1m --cpu-seconds 0 --h2h-steps 0 --two-steps 
 python3 tools/bench_single.py 2>/dev/null > $out/single_and_pcie.json
 python3 tools/bench_files.py --files 4363 --repeat 3 --calls 4 > $out/files.log 2>&1; tail -1 $out/files.log > $out/files_mode.json
 python3 tools/bench_files.py --files 1500 --repeat 3 --calls 4 > $out/files1500.log 2>&1; tail -1 $out/files1500.log > $out/files_mode_1500.json
+python3 tools/bench_files.py --files 4363 --repeat 3 --calls 4 --format cif > $out/files_cif.log 2>&1; tail -1 $out/files_cif.log > $out/files_mode_cif.json
 python3 bench.py --shard-of 8 > $out/shard8.log 2>&1; tail -1 $out/shard8.log > $out/bench_shard_of_8.json
 python3 tools/bench_two_in_flight.py 1 8 2>&1 | grep "^shard" > $out/two_in_flight.txt
 python3 bench.py > $out/bench2.log 2>&1; tail -1 $out/bench2.log > $out/bench_run2.json

@@ -15,7 +15,7 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
                                         "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json", "pmc_uniform1m.txt",
-                                        "files_mode_1500.json", "bench_shard_of_8.json", "two_in_flight.txt", "bench_run2.json")}
+                                        "files_mode_1500.json", "files_mode_cif.json", "bench_shard_of_8.json", "two_in_flight.txt", "bench_run2.json")}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 10:
