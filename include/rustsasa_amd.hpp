@@ -206,6 +206,7 @@ Result<SelectedAtoms> select_by_chain(const Structure &pdb, const OptionValues &
 // test hook: directory mode's per-file work (level 0 atom, 1 residue, 2 chain, 3 protein) as JSON, through its short
 // cut for plain PDB files (`fast`) or the general reader; no GPU (tests/test_host_api.py)
 std::string debug_prepare_json(const std::string &path, const OptionValues &o, int level, bool fast);
+double debug_prepare_seconds(const std::string &path, const OptionValues &o, int level, bool fast, int reps, size_t *n_atoms, bool *used_fast);
 Result<std::vector<float>> run_hot_path(const OptionValues &o, const std::vector<rsasa_atom_t> &atoms);
 template <typename Level>
 std::vector<Result<typename Level::Output>> process_many(const std::vector<const Structure *> &pdbs,

@@ -23,6 +23,10 @@
 #include <stdexcept>
 #include <thread>
 #include <type_traits>
+#if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>  // (the mmCIF short cut finds a row's separators sixteen bytes at a time)
+#define RSASA_ROW_SSE2 1
+#endif
 
 namespace rustsasa {
 
@@ -1190,6 +1194,130 @@ bool fast_pdb_prepare(const std::string &text, const OptionValues &o, SegKind ki
 // model keeps chains, residues and one named conformer each.  The exits are the PDB short cut's: an alternate location,
 // a chain or residue that comes back or goes down, a second name inside a residue, a row that is not exactly the
 // header's columns, a missing element or radius, a second `_atom_site` loop - the general reader takes the file.
+// white space as tokenize_views sees it, one table look-up per character
+struct SpaceTable {
+    bool is[256] = {};
+    SpaceTable() { is[(unsigned char)' '] = true; for (int c = '\t'; c <= '\r'; c++) is[c] = true; }
+};
+static const SpaceTable kSpaceTable;
+
+// tokenize_views into a fixed array (no allocation, no bounds growth); returns the number of tokens, cap + 1 if there
+// are more than cap
+inline size_t tokenize_row(const char *p, size_t n, TextView *out, size_t cap)
+{
+    const bool *const sp = kSpaceTable.is;
+    size_t i = 0, k = 0;
+    while (i < n) {
+        while (i < n && sp[(unsigned char)p[i]]) i++;
+        if (i >= n) break;
+        if (k == cap) return cap + 1;
+        if (p[i] == '\'' || p[i] == '"') {
+            const char q = p[i++];
+            size_t j = i;
+            while (j < n && !(p[j] == q && (j + 1 == n || sp[(unsigned char)p[j + 1]]))) j++;
+            out[k++] = {p + i, j - i};
+            i = j + 1;
+        } else {
+            size_t j = i + 1;
+            while (j < n && !sp[(unsigned char)p[j]]) j++;
+            out[k++] = {p + i, j - i};
+            i = j;
+        }
+    }
+    return k;
+}
+
+// The rows of an `_atom_site` loop are written in aligned columns by most writers (AlphaFold's among them): nearly every
+// row has its separators where the row before had them.  RowSplitter keeps the last row's separator mask and token
+// bounds; a row with the same mask gets its tokens by adding offsets.  The mask is built sixteen bytes at a time (SSE2);
+// rows that hold a quote, a tab or another control character, a byte above 127, or more than 256 bytes - and builds
+// without SSE2 - go through tokenize_row.  Either way the tokens are tokenize_views'.
+struct RowSplitter {
+    static constexpr size_t kMaxCols = 64;
+    TextView tok[kMaxCols];
+    size_t n_tok = 0;
+#ifdef RSASA_ROW_SSE2
+    uint64_t last_mask[4] = {~0ull, ~0ull, ~0ull, ~0ull};  // bit i: byte i is a blank (or beyond the row's end)
+    uint16_t off[kMaxCols], len[kMaxCols];
+    size_t last_n = 0;
+    bool have_last = false;
+#endif
+
+    // false: more than kMaxCols tokens
+    bool split(const char *p, size_t n, const char *text_end)
+    {
+#ifdef RSASA_ROW_SSE2
+        if (n <= 256) {
+            uint64_t m[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+            const __m128i blank = _mm_set1_epi8(' '), q1 = _mm_set1_epi8('\''), q2 = _mm_set1_epi8('"');
+            unsigned odd = 0;  // quotes, control characters, bytes above 127 (signed compare: below ' ')
+            for (size_t b = 0; b < n; b += 16) {
+                __m128i v;
+                if (p + b + 16 <= text_end) {
+                    v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p + b));
+                } else {
+                    char tmp[16] = {' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' ', ' '};
+                    std::memcpy(tmp, p + b, (size_t)(text_end - (p + b)));
+                    v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(tmp));
+                }
+                uint32_t sp = (uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(v, blank));
+                uint32_t bad = (uint32_t)_mm_movemask_epi8(_mm_or_si128(_mm_cmplt_epi8(v, blank), _mm_or_si128(_mm_cmpeq_epi8(v, q1), _mm_cmpeq_epi8(v, q2))));
+                if (n - b < 16) {  // bytes beyond the row: blanks, whatever they are
+                    const uint32_t in_row = (1u << (n - b)) - 1u;
+                    sp |= ~in_row & 0xFFFFu;
+                    bad &= in_row;
+                }
+                odd |= bad;
+                m[b >> 6] = (m[b >> 6] & ~(0xFFFFull << (b & 63))) | ((uint64_t)sp << (b & 63));
+            }
+            if (!odd) {
+                if (have_last && m[0] == last_mask[0] && m[1] == last_mask[1] && m[2] == last_mask[2] && m[3] == last_mask[3]) {
+                    for (size_t k = 0; k < n_tok; k++) tok[k] = {p + off[k], len[k]};
+                    return true;
+                }
+                // token bounds from the mask: every change of state, in order
+                size_t k = 0;
+                bool in_tok = false;
+                size_t start = 0;
+                uint64_t carry = 1;  // (the byte before the row counts as a blank)
+                for (size_t w = 0; w * 64 < n; w++) {
+                    const uint64_t sp = m[w];
+                    uint64_t edges = sp ^ ((sp << 1) | carry);
+                    carry = sp >> 63;
+                    while (edges) {
+                        const size_t pos = w * 64 + (size_t)__builtin_ctzll(edges);
+                        edges &= edges - 1;
+                        if (!in_tok) {
+                            if (k == kMaxCols) return false;
+                            start = pos;
+                        } else {
+                            off[k] = (uint16_t)start; len[k] = (uint16_t)(pos - start);
+                            tok[k] = {p + start, pos - start};
+                            k++;
+                        }
+                        in_tok = !in_tok;
+                    }
+                }
+                if (in_tok) {  // (n is a multiple of 64 and the last token ends with the row)
+                    off[k] = (uint16_t)start; len[k] = (uint16_t)(n - start);
+                    tok[k] = {p + start, n - start};
+                    k++;
+                }
+                n_tok = k;
+                for (int w = 0; w < 4; w++) last_mask[w] = m[w];
+                last_n = n;
+                have_last = true;
+                return true;
+            }
+            have_last = false;
+        }
+#endif
+        (void)text_end;
+        n_tok = tokenize_row(p, n, tok, kMaxCols);
+        return n_tok <= kMaxCols;
+    }
+};
+
 bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind kind, Structure &light, Prepared &p)
 {
     if (o.radii_config) return false;
@@ -1197,9 +1325,11 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
     std::pmr::memory_resource *const mem = light.chains.get_allocator().resource();
     p.atoms.clear();
     p.seg_end.clear();
-    p.atoms.reserve(text.size() / 96 + 1);
+    p.atoms.reserve(text.size() / 88 + 1);
     std::vector<std::string> cols;
-    static thread_local std::vector<TextView> tok;
+    constexpr size_t kMaxCols = RowSplitter::kMaxCols;
+    RowSplitter rows;
+    TextView *const tok = rows.tok;
     bool in_loop = false, in_atom_site = false, resolved = false, had_rows = false;
     std::string first_model;
     int c_group = -1, c_id = -1, c_sym = -1, c_atom = -1, c_alt = -1, c_comp = -1, c_lasym = -1, c_aasym = -1, c_lseq = -1,
@@ -1214,17 +1344,21 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
         const TextView &t = tok[(size_t)c];
         return (t.second == 1 && (t.first[0] == '.' || t.first[0] == '?')) ? TextView{t.first, 0} : t;
     };
+    auto eq = [](const TextView &a, const TextView &b) { return a.second == b.second && std::memcmp(a.first, b.first, a.second) == 0; };
+    // the current residue, as views of its first row (the model's strings hold the same characters)
     bool have_res = false;
     std::int64_t res_seq = 0;
+    TextView res_chain{"", 0}, res_icode{"", 0}, res_comp{"", 0};
     const char *cur = text.data(), *const end = text.data() + text.size();
     while (cur < end) {
         const LineView raw = next_line(cur, end);
         const TextView tv = field_view(raw, 1, raw.n);  // trimmed
         if (tv.second == 0) continue;
         const LineView t{tv.first, tv.second};
-        if (t.n == 5 && t.starts_with("loop_")) { in_loop = true; in_atom_site = false; cols.clear(); resolved = false; continue; }
+        if (t[0] == 'l' && t.n == 5 && t.starts_with("loop_")) { in_loop = true; in_atom_site = false; cols.clear(); resolved = false; continue; }
         if (t[0] == '#') { in_loop = false; in_atom_site = false; continue; }
-        if (in_loop && t[0] == '_') {
+        if (t[0] == '_') {
+            if (!in_loop) continue;
             if (t.starts_with("_atom_site.")) {
                 if (had_rows) return false;  // a second loop of atoms
                 in_atom_site = true;
@@ -1237,7 +1371,6 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
             continue;
         }
         if (!(in_loop && in_atom_site)) continue;
-        if (t[0] == '_') { in_loop = false; continue; }
         if (!resolved) {
             c_group = col("group_PDB"); c_id = col("id"); c_sym = col("type_symbol");
             c_atom = col("label_atom_id"); c_alt = col("label_alt_id"); c_comp = col("label_comp_id");
@@ -1246,29 +1379,27 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
             c_y = col("Cartn_y"); c_z = col("Cartn_z"); c_occ = col("occupancy"); c_model = col("pdbx_PDB_model_num");
             resolved = true;
             if (c_x < 0 || c_y < 0 || c_z < 0 || c_atom < 0 || c_comp < 0) return false;  // (the general reader reports it)
+            if (cols.size() > kMaxCols) return false;
         }
-        tokenize_views(t, tok);
-        if (tok.size() != cols.size()) return false;
+        if (!rows.split(t.p, t.n, end) || rows.n_tok != cols.size()) return false;
         had_rows = true;
         const TextView model_id = val(c_model);
         if (first_model.empty()) first_model = model_id.second ? std::string(model_id.first, model_id.second) : "1";
         if (model_id.second && !same(first_model, model_id)) continue;
         if (val(c_alt).second) return false;
-        const TextView chain_id = c_aasym >= 0 && val(c_aasym).second ? val(c_aasym) : val(c_lasym);
-        const TextView seq_t = c_aseq >= 0 && val(c_aseq).second ? val(c_aseq) : val(c_lseq);
+        TextView chain_id = val(c_aasym);
+        if (!chain_id.second) chain_id = val(c_lasym);
+        TextView seq_t = val(c_aseq);
+        if (!seq_t.second) seq_t = val(c_lseq);
         const std::int64_t seq = token_long(seq_t);
         const TextView icode = val(c_ins), comp = val(c_comp), name = val(c_atom), group = val(c_group);
-        const bool same_chain = !light.chains.empty() && same(light.chains.back().id, chain_id);
-        bool same_res = false;
-        if (same_chain && have_res) {
-            const Residue &prev = light.chains.back().residues.back();
-            same_res = seq == res_seq && same(prev.insertion_code, icode);
-            if (same_res && !same(prev.conformers.front().name, comp)) return false;  // a second conformer
-        }
-        if (!same_res) {
+        const bool same_chain = have_res && eq(res_chain, chain_id);
+        const bool same_res = same_chain && seq == res_seq && eq(res_icode, icode);
+        if (same_res) {
+            if (!eq(res_comp, comp)) return false;  // a second conformer
+        } else {
             if (same_chain) {
-                const Residue &prev = light.chains.back().residues.back();
-                const int c = prev.insertion_code.compare(0, std::string::npos, icode.first, icode.second);
+                const int c = std::string_view(res_icode.first, res_icode.second).compare(std::string_view(icode.first, icode.second));
                 if (!(seq > res_seq || (seq == res_seq && c < 0))) return false;
             } else {
                 for (const Chain &ch : light.chains)
@@ -1283,6 +1414,7 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
                 Conformer{std::string(comp.first, comp.second), std::string(), std::pmr::vector<AtomRecord>(mem)});
             have_res = true;
             res_seq = seq;
+            res_chain = chain_id; res_icode = icode; res_comp = comp;
         }
         // element: the symbol in upper case, else the first letter of the name (set_element); hydrogen / HETATM filters
         const TextView sym = val(c_sym);
@@ -1327,6 +1459,39 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
 }
 
 }  // namespace
+
+// Measurement hook (sasa_host_cli prepare-bench-*): seconds per pass of directory mode's per-file work - text to kept
+// atoms - through the short cut or the general reader, the file read once; no GPU.
+double debug_prepare_seconds(const std::string &path, const OptionValues &o, int level, bool fast, int reps, size_t *n_atoms, bool *used_fast)
+{
+    const std::string text = read_whole_file(path);
+    const bool cif = is_mmcif_path(path);
+    const SegKind kinds[] = {SegKind::None, SegKind::Residue, SegKind::Chain, SegKind::Residue};
+    size_t atoms = 0;
+    bool took_fast = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++) {
+        Prepared p;
+        bool ok = false;
+        if (fast) {
+            Structure light(text.size() / 8 + 4096);
+            ok = cif ? fast_cif_prepare(text, o, kinds[level], light, p) : fast_pdb_prepare(text, o, kinds[level], light, p);
+        }
+        took_fast = ok;
+        if (!ok) {
+            t_skip_occupancy_and_bfactor = !o.read_radii_from_occupancy;
+            const Structure model = cif ? Structure::from_mmcif_text(text) : Structure::from_pdb_text(text);
+            t_skip_occupancy_and_bfactor = false;
+            p = level == 0 ? prepare<AtomLevel>(model, o) : level == 1 ? prepare<ResidueLevel>(model, o)
+              : level == 2 ? prepare<ChainLevel>(model, o) : prepare<ProteinLevel>(model, o);
+        }
+        atoms = p.atoms.size();
+    }
+    const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
+    if (n_atoms) *n_atoms = atoms;
+    if (used_fast) *used_fast = took_fast;
+    return s;
+}
 
 // Test hook (sasa_host_cli prepare): what directory mode hands to the GPU for one file - kept atoms, segment ends - and
 // the model its results take their metadata from, through the short cut (`fast`, when the file qualifies) or the

@@ -279,6 +279,18 @@ int main(int argc, char **argv)
             for (int i = 3; i + 1 < argc; i++)
                 if (!std::strcmp(argv[i], "--level")) lv = std::atoi(argv[i + 1]);
             std::printf("%s\n", detail::debug_prepare_json(argv[2], make<ChainLevel>(argc, argv).values(), lv, level == "prepare-fast").c_str());
+        } else if (level == "prepare-bench-fast" || level == "prepare-bench-general") {
+            // the same work timed: `--reps N` passes over the file's text (read once), no GPU
+            int lv = 1, reps = 20;
+            for (int i = 3; i + 1 < argc; i++) {
+                if (!std::strcmp(argv[i], "--level")) lv = std::atoi(argv[i + 1]);
+                if (!std::strcmp(argv[i], "--reps")) reps = std::atoi(argv[i + 1]);
+            }
+            size_t atoms = 0;
+            bool used_fast = false;
+            const double sec = detail::debug_prepare_seconds(argv[2], make<ChainLevel>(argc, argv).values(), lv, level == "prepare-bench-fast", reps, &atoms, &used_fast);
+            std::printf("{\"fast\":%s,\"atoms\":%zu,\"seconds_per_pass\":%.6g,\"ns_per_atom\":%.1f}\n", used_fast ? "true" : "false", atoms, sec,
+                        atoms ? sec * 1e9 / (double)atoms : 0.0);
         } else if (level == "rewrite") {  // reader -> writer round trip, no GPU
             std::printf("%s", pdb.to_pdb_text().c_str());
         } else if (level == "parse") {  // reader only (no GPU): atom / residue / chain counts

@@ -408,7 +408,9 @@ def test_directory_modes_mmcif_short_cut_equals_the_general_reader(tmp_path):
     rewritten as `_atom_site` loops, and mutants of them that hit the short cut's exits - an alternate location, a chain
     that comes back, rows swapped, a row with a token too few or too many, no element symbol, an atom without a radius,
     a second model, a residue number that goes back, a second name inside a residue, an insertion code, a serial number
-    that is not one, a HETATM inside a residue, '?' for a coordinate, an early residue repeated later, a second loop."""
+    that is not one, a HETATM inside a residue, '?' for a coordinate, an early residue repeated later, a second loop; and
+    rows that the aligned-column row splitter must not mis-split: tabs, quoted names, other column positions, a row of
+    more than 256 bytes, a byte above 127, a token wider than its column."""
     rng = np.random.default_rng(11)
     texts = {"example.cif": open(sio.data_path("example.cif")).read()}
     for name in ["151L_H3.pdb", "bad_seqadv_1A06.pdb", "1jcd.pdb", "2drt.pdb", "freesasa/2gpi.pdb", "freesasa/4c1a.pdb"]:
@@ -417,10 +419,10 @@ def test_directory_modes_mmcif_short_cut_equals_the_general_reader(tmp_path):
                    ("--read-radii-from-occupancy",)]
     n_fast = n_cases = 0
 
-    def compare(path, label):
+    def compare(path, label, levels=(0, 1, 2, 3), sets=option_sets):
         nonlocal n_fast, n_cases
-        for level in (0, 1, 2, 3):
-            for opts in option_sets:
+        for level in levels:
+            for opts in sets:
                 a, b = _prepare_json(path, level, True, *opts), _prepare_json(path, level, False, *opts)
                 n_fast += a.pop("fast")
                 b.pop("fast")
@@ -433,7 +435,7 @@ def test_directory_modes_mmcif_short_cut_equals_the_general_reader(tmp_path):
         compare(base, name)
         lines = text.split("\n")
         atom_idx = [i for i, l in enumerate(lines) if l.startswith(("ATOM ", "HETATM "))]
-        for kind in range(16):
+        for kind in range(23):
             mut = list(lines)
             i = int(rng.choice(atom_idx[5:-5]))
             f = mut[i].split()
@@ -459,9 +461,17 @@ def test_directory_modes_mmcif_short_cut_equals_the_general_reader(tmp_path):
             elif kind == 14: mut[i] = mut[i] + " extra"                                 # a token too many
             elif kind == 15: mut = mut[:i] + ["#", "loop_", "_atom_site.Cartn_x", "_atom_site.Cartn_y", "_atom_site.Cartn_z",
                                                "_atom_site.label_atom_id", "_atom_site.label_comp_id", "1.0 2.0 3.0 CA ALA"] + ["#"]  # rows cut short, a second loop
+            # rows the aligned-column splitter must hand to the character-wise tokenizer, or split differently
+            elif kind == 16: mut[i] = mut[i].replace(" ", "\t", 3)                      # tabs between tokens
+            elif kind == 17: mut[i] = put(3, '"%s"' % f[3])                             # a quoted atom name
+            elif kind == 18: mut[i] = put(3, "'%s'" % f[3])                             # ... in single quotes
+            elif kind == 19: mut[i] = "   " + mut[i].replace(" ", "   ", 5) + "    "    # other column positions, blanks around
+            elif kind == 20: mut[i] = put(16, "1." + "0" * 300)                         # a row of more than 256 bytes
+            elif kind == 21: mut[i] = put(5, "\u00c5LA")                                # a byte above 127
+            elif kind == 22: mut[i] = put(1, str(10 ** 7 + i))                          # a wider token: the columns shift
             path = tmp_path / f"mut_{os.path.basename(name)}_{kind}.cif"
             path.write_text("\n".join(mut))
-            compare(path, f"{name} mutant {kind}")
+            compare(path, f"{name} mutant {kind}", (1, 2), option_sets[:2] if kind % 2 else option_sets[2:])
     assert n_fast > 60 and n_cases - n_fast > 60, (n_fast, n_cases)  # both routes were exercised
 
 
