@@ -400,7 +400,8 @@ def config5_leg(ctx, dev, steps, with_ids):
 def files_leg(n_files):
     """Directory mode (reference src/main.rs:342-480): n synthetic PDB files on /dev/shm -> per-residue values through
     the C++ host API's process_files (sasa_host_cli, its own process: parse threads + GPU batches), three calls in one
-    process.  The files are written here (untimed)."""
+    process; then the same structures as AlphaFold-style mmCIF files (`mmcif`: the format BASELINE.json's config names).
+    The files are written here (untimed)."""
     import shutil
     import tempfile
     import numpy as np
@@ -409,34 +410,41 @@ def files_leg(n_files):
     import bench_files as bf
     cli = os.path.join(ROOT, "rustsasa_amd", "lib", "sasa_host_cli")
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
-    d = tempfile.mkdtemp(prefix="rsasa_bench_files_", dir=base)
-    try:
-        rng = np.random.default_rng(bw.PROTEOME_SEED)
-        sizes = np.clip(rng.lognormal(np.log(2000.0), 0.75, n_files), 150, 25000).astype(int)
-        doms = bf.load_domains()
-        paths, atoms = [], 0
-        for i, n_t in enumerate(sizes):
-            p = os.path.join(d, f"s{i:05d}.pdb")
-            atoms += bf.write_structure(p, int(n_t), rng, doms)
-            paths.append(p)
-        lst = os.path.join(d, "files.txt")
-        open(lst, "w").write("\n".join(paths) + "\n")
-        nbytes = sum(os.path.getsize(p) for p in paths)
-        p = subprocess.run([cli, "files", "residue", lst, "--threads", "0", "--batch", "0", "--workers", "0",
-                            "--devices", "1", "--calls", "3"], capture_output=True, text=True, timeout=600)
-        if p.returncode != 0:
-            return {"error": p.stderr[-300:]}
-        r = json.loads(p.stdout)
-        calls = r["calls_s"]
-        return {"files": n_files, "atoms": int(atoms), "bytes_on_disk": int(nbytes),
-                "files_per_s": round(n_files / calls[0], 1),
-                "files_per_s_later_calls": round(n_files / min(calls[1:]), 1) if len(calls) > 1 else None,
-                "calls_s": [round(c, 4) for c in calls], "host_threads": os.cpu_count(),
-                "note": "files_per_s: the first process_files call of a fresh process (HIP start-up inside); later calls "
-                        "of the same process: files_per_s_later_calls; PDB text on /dev/shm, parse + selection + GPU + "
-                        "ResidueLevel results on the host"}
-    finally:
-        shutil.rmtree(d, ignore_errors=True)
+    doms = bf.load_domains()
+
+    def one(ext):
+        d = tempfile.mkdtemp(prefix="rsasa_bench_files_", dir=base)
+        try:
+            rng = np.random.default_rng(bw.PROTEOME_SEED)
+            sizes = np.clip(rng.lognormal(np.log(2000.0), 0.75, n_files), 150, 25000).astype(int)
+            paths, atoms = [], 0
+            for i, n_t in enumerate(sizes):
+                p = os.path.join(d, f"s{i:05d}.{ext}")
+                atoms += bf.write_structure(p, int(n_t), rng, doms, cif=ext == "cif")
+                paths.append(p)
+            lst = os.path.join(d, "files.txt")
+            open(lst, "w").write("\n".join(paths) + "\n")
+            nbytes = sum(os.path.getsize(p) for p in paths)
+            p = subprocess.run([cli, "files", "residue", lst, "--threads", "0", "--batch", "0", "--workers", "0",
+                                "--devices", "1", "--calls", "3"], capture_output=True, text=True, timeout=600)
+            if p.returncode != 0:
+                return {"error": p.stderr[-300:]}
+            calls = json.loads(p.stdout)["calls_s"]
+            return {"files": n_files, "atoms": int(atoms), "bytes_on_disk": int(nbytes),
+                    "files_per_s": round(n_files / calls[0], 1),
+                    "files_per_s_later_calls": round(n_files / min(calls[1:]), 1) if len(calls) > 1 else None,
+                    "calls_s": [round(c, 4) for c in calls]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    r = one("pdb")
+    if "error" in r:
+        return r
+    r.update({"host_threads": os.cpu_count(), "mmcif": one("cif"),
+              "note": "files_per_s: the first process_files call of a fresh process (HIP start-up inside); later calls "
+                      "of the same process: files_per_s_later_calls; PDB text on /dev/shm, parse + selection + GPU + "
+                      "ResidueLevel results on the host; mmcif: the same structures as AlphaFold-style mmCIF files"})
+    return r
 
 
 def main():
