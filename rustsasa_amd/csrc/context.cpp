@@ -1381,7 +1381,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     // Large batches are cut into sub-batches of whole structures (and whole residues) whose
     // host-to-device copies run on a second stream into a second set of input buffers while the
     // previous sub-batch computes: the PCIe transfer hides behind the kernels.
-    const size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
+    size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
+    if (const char *v = std::getenv("RSASA_SUB_ATOMS")) kSubAtoms = (size_t)std::max(100000, std::atoi(v));
     std::vector<size_t> cut{0};        // structure indices where sub-batches begin / end
     if (N >= 2 * kSubAtoms && n_structures > 1) {
         size_t max_sub = 8;
@@ -1426,10 +1427,12 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     DeviceBuffer *bi[kSlots] = {&ctx->in_id, &ctx->in2_id, &ctx->in3_id}, *bo[kSlots] = {&ctx->in_res, &ctx->in2_res, &ctx->in3_res};
     DeviceBuffer *oa[kSlots] = {&ctx->atom_sasa, &ctx->atom_sasa2, &ctx->atom_sasa3};
     DeviceBuffer *orr[kSlots] = {&ctx->out_res, &ctx->out_res2, &ctx->out_res3};
+    const float *dev_x[kSlots] = {}, *dev_y[kSlots] = {}, *dev_z[kSlots] = {};
     for (int k = 0; k < n_slots; k++) {
         if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
         if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
+        dev_x[k] = (const float *)bx[k]->p; dev_y[k] = (const float *)by[k]->p; dev_z[k] = (const float *)bz[k]->p;
         if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
         if (id && !piped && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;  // (pipelined: below, unless the ids are folded)
         if (want_res && !piped && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
@@ -1554,15 +1557,27 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if ((rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
     tr("setup done");
     std::vector<char> use_codes(cut.size(), 0);  // sub-batch c's radii travel as codes (decided once its coding job is done)
+    // the coordinates of a sub-batch do not wait for its coding job (ids, radius codes): they are queued first, and the
+    // first sub-batch's start crossing the link while its block is still being written
+    auto upload_xyz = [&](size_t c, hipStream_t st) -> int {
+        const int k = (int)(c % kSlots);
+        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
+        if (na) {
+            // (one hipMemcpy2DAsync of three rows for x, y, z a fixed distance apart runs at the link's rate by itself -
+            // tools/microbench_copy2d.hip - but is a kernel: behind the occlusion kernels it waits for CUs, and the call
+            // took 6.5 instead of 5.1 ms)
+            RS_HIP(ctx, hipMemcpyAsync(bx[k]->p, x + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
+        }
+        return RSASA_OK;
+    };
     auto upload = [&](size_t c, hipStream_t st) -> int {
         const int k = (int)(c % kSlots);
         const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
         so[k].resize(s1 - s0 + 1);
         for (size_t i = s0; i <= s1; i++) so[k][i - s0] = structure_offsets[i] - (uint32_t)a0;
         if (na) {
-            RS_HIP(ctx, hipMemcpyAsync(bx[k]->p, x + a0, na * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
             if (!use_codes[c]) RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
             if (!fold_ids && id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
         }
@@ -1589,9 +1604,9 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
         const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
         rsasa_device_batch_t bt{};
-        bt.x = (const float *)bx[k]->p;
-        bt.y = (const float *)by[k]->p;
-        bt.z = (const float *)bz[k]->p;
+        bt.x = dev_x[k];
+        bt.y = dev_y[k];
+        bt.z = dev_z[k];
         bt.radius = (const float *)br[k]->p;
         bt.id = id ? (const uint64_t *)bi[k]->p : nullptr;
         bt.structure_offsets_host = so[k].data();
@@ -1638,6 +1653,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     };
     if (!piped) {
         // one sub-batch: upload, kernels, wait (re-runs with a larger cell array if needed), copy out
+        if ((rc = upload_xyz(0, st))) return rc;
         if ((rc = upload(0, st))) return rc;
         if ((rc = enqueue(0))) return rc;
         const size_t na = structure_offsets[cut[1]], nr = want_res ? res_cut[1] : 0;
@@ -1701,6 +1717,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 check(k);
                 if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
             }
+            if ((rc = upload_xyz(c, cp))) return rc;
             if (fold_ids || code_radii) ctx->fold_pool->wait(fold_job[c]);
             use_codes[c] = code_radii && !ctx->radius_codec.failed.load();
             if (c == 0) tr("first sub-batch coded");
@@ -1716,9 +1733,9 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
             const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
             Pending pd;
-            pd.batch.x = (const float *)bx[k]->p;
-            pd.batch.y = (const float *)by[k]->p;
-            pd.batch.z = (const float *)bz[k]->p;
+            pd.batch.x = dev_x[k];
+            pd.batch.y = dev_y[k];
+            pd.batch.z = dev_z[k];
             pd.batch.radius = (const float *)br[k]->p;
             pd.batch.id = fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
             const char *dblk = (const char *)ctx->in_pack[k].p;

@@ -2,15 +2,17 @@
 # Timeline of one host-to-host proteome call: kernels and memory copies (rocprofv3 traces), summarised per call.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/h2h_trace
+export H2H_SORTED=1  # bench.py's order: largest structures first
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/h2h_trace -- python3 tools/bench_h2h.py 8 > /dev/null 2>&1
 python3 - <<'P'
-import csv, glob
+import csv, glob, re
 kt = glob.glob("gpurun_out/h2h_trace/**/*kernel_trace.csv", recursive=True)[0]
 mt = glob.glob("gpurun_out/h2h_trace/**/*memory_copy_trace.csv", recursive=True)[0]
 ev = []
 for r in csv.DictReader(open(kt)):
     if "rsasa" in r["Kernel_Name"]:
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K", r["Kernel_Name"].split("::")[-1][:24]))
+        m = re.search(r"k_\w+", r["Kernel_Name"])
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K", m.group(0) if m else r["Kernel_Name"][:24]))
 rows = list(csv.DictReader(open(mt)))
 print("copy columns:", list(rows[0].keys()))
 for r in rows:
@@ -28,6 +30,6 @@ for e in sel:
         gap = (e[0] - prev_c) / 1e3 if prev_c else 0
         prev_c = e[1]
         print(f"{(e[0]-t0)/1e3:9.1f} us  copy {e[3]:28s} {(e[1]-e[0])/1e3:8.1f} us  gap since previous copy {gap:7.1f}")
-    elif "mx" in e[3] or "sort_window" in e[3]:
-        print(f"{(e[0]-t0)/1e3:9.1f} us  kernel {e[3]:26s} {(e[1]-e[0])/1e3:8.1f} us")
+    elif e[2] == "K" and (e[1] - e[0]) > 15000:
+        print(f"{(e[0]-t0)/1e3:9.1f} us  kernel {e[3]:26s} {(e[1]-e[0])/1e3:8.1f} us   ends {(e[1]-t0)/1e3:9.1f}")
 P
