@@ -3,7 +3,7 @@
 
     python tools/fuzz_reader.py [--asan] [-n 400]
 
-Feeds mutated copies of the fixture files to `sasa_host_cli parse|rewrite` and reports any run that
+Feeds mutated copies of the fixture files to `sasa_host_cli parse|rewrite|prepare-fast` and reports any run that
 dies from a signal or prints a sanitizer report.  --asan first builds the host layer with
 `g++ -fsanitize=address,undefined` (CPU only; GPU sanitizers are not available on this pool).
 tests/test_reader_fuzz.py runs a short round of the same mutations with the regular build.
@@ -71,8 +71,11 @@ def run_cases(cli, n, seed=7, workdir=None):
             p = os.path.join(d, f"c{it}{os.path.splitext(name)[1]}")
             with open(p, "wb") as f:
                 f.write(data)
-            for mode in ("parse", "rewrite"):
-                r = subprocess.run([cli, mode, p], capture_output=True, timeout=120)
+            # parse / rewrite: the general reader and the writer; prepare-fast: directory mode's short cuts
+            # (fast_pdb_prepare / fast_cif_prepare, falling back to the general reader + selection)
+            for mode in ("parse", "rewrite", "prepare-fast"):
+                r = subprocess.run([cli, mode, p] + (["--level", str(it % 4), "--allow-vdw-fallback"] if mode == "prepare-fast" else []),
+                                   capture_output=True, timeout=120)
                 if r.returncode < 0 or b"Sanitizer" in r.stderr or b"runtime error" in r.stderr:
                     failures.append((it, kind, mode, r.returncode, r.stderr[-400:].decode(errors="replace")))
             os.remove(p)
@@ -98,7 +101,7 @@ def main():
     bad = run_cases(cli, args.n)
     for f in bad:
         print("FAIL", *f)
-    print(f"{args.n} mutated files x 2 modes, {len(bad)} crashes")
+    print(f"{args.n} mutated files x 3 modes, {len(bad)} crashes")
     sys.exit(1 if bad else 0)
 
 
