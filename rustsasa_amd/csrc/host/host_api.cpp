@@ -1234,18 +1234,19 @@ inline size_t tokenize_row(const char *p, size_t n, TextView *out, size_t cap)
 // without SSE2 - go through tokenize_row.  Either way the tokens are tokenize_views'.
 struct RowSplitter {
     static constexpr size_t kMaxCols = 64;
-    TextView tok[kMaxCols];
+    const char *row = nullptr;          // the current row; token k is row + off[k], len[k] bytes
+    uint16_t off[kMaxCols], len[kMaxCols];
     size_t n_tok = 0;
 #ifdef RSASA_ROW_SSE2
     uint64_t last_mask[4] = {~0ull, ~0ull, ~0ull, ~0ull};  // bit i: byte i is a blank (or beyond the row's end)
-    uint16_t off[kMaxCols], len[kMaxCols];
-    size_t last_n = 0;
     bool have_last = false;
 #endif
+    TextView token(size_t k) const { return {row + off[k], len[k]}; }
 
-    // false: more than kMaxCols tokens
+    // false: more than kMaxCols tokens (or a row too long for 16-bit offsets)
     bool split(const char *p, size_t n, const char *text_end)
     {
+        row = p;
 #ifdef RSASA_ROW_SSE2
         if (n <= 256) {
             uint64_t m[4] = {~0ull, ~0ull, ~0ull, ~0ull};
@@ -1271,10 +1272,8 @@ struct RowSplitter {
                 m[b >> 6] = (m[b >> 6] & ~(0xFFFFull << (b & 63))) | ((uint64_t)sp << (b & 63));
             }
             if (!odd) {
-                if (have_last && m[0] == last_mask[0] && m[1] == last_mask[1] && m[2] == last_mask[2] && m[3] == last_mask[3]) {
-                    for (size_t k = 0; k < n_tok; k++) tok[k] = {p + off[k], len[k]};
-                    return true;
-                }
+                if (have_last && m[0] == last_mask[0] && m[1] == last_mask[1] && m[2] == last_mask[2] && m[3] == last_mask[3])
+                    return true;  // the previous row's columns: off / len stand
                 // token bounds from the mask: every change of state, in order
                 size_t k = 0;
                 bool in_tok = false;
@@ -1292,7 +1291,6 @@ struct RowSplitter {
                             start = pos;
                         } else {
                             off[k] = (uint16_t)start; len[k] = (uint16_t)(pos - start);
-                            tok[k] = {p + start, pos - start};
                             k++;
                         }
                         in_tok = !in_tok;
@@ -1300,12 +1298,10 @@ struct RowSplitter {
                 }
                 if (in_tok) {  // (n is a multiple of 64 and the last token ends with the row)
                     off[k] = (uint16_t)start; len[k] = (uint16_t)(n - start);
-                    tok[k] = {p + start, n - start};
                     k++;
                 }
                 n_tok = k;
                 for (int w = 0; w < 4; w++) last_mask[w] = m[w];
-                last_n = n;
                 have_last = true;
                 return true;
             }
@@ -1313,8 +1309,12 @@ struct RowSplitter {
         }
 #endif
         (void)text_end;
-        n_tok = tokenize_row(p, n, tok, kMaxCols);
-        return n_tok <= kMaxCols;
+        if (n > 0xFFFFu) return false;
+        TextView tmp[kMaxCols];
+        n_tok = tokenize_row(p, n, tmp, kMaxCols);
+        if (n_tok > kMaxCols) return false;
+        for (size_t k = 0; k < n_tok; k++) { off[k] = (uint16_t)(tmp[k].first - p); len[k] = (uint16_t)tmp[k].second; }
+        return true;
     }
 };
 
@@ -1329,7 +1329,6 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
     std::vector<std::string> cols;
     constexpr size_t kMaxCols = RowSplitter::kMaxCols;
     RowSplitter rows;
-    TextView *const tok = rows.tok;
     bool in_loop = false, in_atom_site = false, resolved = false, had_rows = false;
     std::string first_model;
     int c_group = -1, c_id = -1, c_sym = -1, c_atom = -1, c_alt = -1, c_comp = -1, c_lasym = -1, c_aasym = -1, c_lseq = -1,
@@ -1341,7 +1340,7 @@ bool fast_cif_prepare(const std::string &text, const OptionValues &o, SegKind ki
     };
     auto val = [&](int c) -> TextView {  // "." and "?" stand for no value
         if (c < 0) return {"", 0};
-        const TextView &t = tok[(size_t)c];
+        const TextView t = rows.token((size_t)c);
         return (t.second == 1 && (t.first[0] == '.' || t.first[0] == '?')) ? TextView{t.first, 0} : t;
     };
     auto eq = [](const TextView &a, const TextView &b) { return a.second == b.second && std::memcmp(a.first, b.first, a.second) == 0; };
