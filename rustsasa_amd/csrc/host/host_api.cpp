@@ -1309,6 +1309,9 @@ struct RowSplitter {
         }
 #endif
         (void)text_end;
+#ifdef RSASA_ROW_SSE2
+        have_last = false;  // (off / len are overwritten below: the remembered mask no longer describes them)
+#endif
         if (n > 0xFFFFu) return false;
         TextView tmp[kMaxCols];
         n_tok = tokenize_row(p, n, tmp, kMaxCols);
