@@ -188,16 +188,25 @@ int main(int argc, char **argv)
                     for (size_t i = 0; i < v.size(); i++) std::printf("%s%.9g", i ? "," : "", v[i]);
                     std::printf("]");
                 });
+            // --labels: every value with its chain id, ["A", value] (the quality gate sums per chain: tests/quality.rs:60-100)
+            bool labels = false;
+            for (int i = 4; i < argc; i++) labels |= !std::strcmp(argv[i], "--labels");
             if (level == "residue")
-                return run_files<ResidueLevel>(argc, argv, [](const std::vector<ResidueResult> &v) {
+                return run_files<ResidueLevel>(argc, argv, [labels](const std::vector<ResidueResult> &v) {
                     std::printf("[");
-                    for (size_t i = 0; i < v.size(); i++) std::printf("%s%.9g", i ? "," : "", v[i].value);
+                    for (size_t i = 0; i < v.size(); i++) {
+                        if (labels) std::printf("%s[\"%s\",%.9g]", i ? "," : "", v[i].chain_id.c_str(), v[i].value);
+                        else std::printf("%s%.9g", i ? "," : "", v[i].value);
+                    }
                     std::printf("]");
                 });
             if (level == "chain")
-                return run_files<ChainLevel>(argc, argv, [](const std::vector<ChainResult> &v) {
+                return run_files<ChainLevel>(argc, argv, [labels](const std::vector<ChainResult> &v) {
                     std::printf("[");
-                    for (size_t i = 0; i < v.size(); i++) std::printf("%s%.9g", i ? "," : "", v[i].value);
+                    for (size_t i = 0; i < v.size(); i++) {
+                        if (labels) std::printf("%s[\"%s\",%.9g]", i ? "," : "", v[i].name.c_str(), v[i].value);
+                        else std::printf("%s%.9g", i ? "," : "", v[i].value);
+                    }
                     std::printf("]");
                 });
             if (level == "protein")

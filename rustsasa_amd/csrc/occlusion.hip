@@ -248,3 +248,13 @@ void launch_occlusion_deferred(const BatchView &b, const Lattice &lat, hipStream
 }
 
 }  // namespace rsasa
+
+#ifdef MX_STAGE_PROF
+// diagnostic build only (tools/mx_stage_prof.py): the stage stamps of k_occlusion_mx summed over every wave since the last call
+extern "C" __attribute__((visibility("default"))) int rsasa_debug_mx_prof(unsigned long long *out)
+{
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rsasa::g_mx_prof), sizeof(zero)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(rsasa::g_mx_prof), zero, sizeof(zero)) != hipSuccess;
+}
+#endif

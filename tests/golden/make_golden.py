@@ -7,10 +7,12 @@ on the GPU box).  Fixtures are DATA: the reference's own test inputs
 FIXED_LOW_RES_ATOMS (tests/common/data.rs:4-238), written one value per line.
 No reference source text is stored.
 """
+import io
 import os
 import re
 import shutil
 import sys
+import tarfile
 
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +46,20 @@ def main():
             dst = os.path.join(HERE, "data", "freesasa", os.path.basename(rel))
             shutil.copyfile(os.path.join(REF, rel), dst)
             os.chmod(dst, 0o644)
+
+    # The WHOLE quality set (tests/quality.rs:200-258: 88 PDB files, 46 MB, and FreeSASA's chain totals for each) as one
+    # xz archive: the GPU test sends all of it through process_files in one batch.  Sorted names, fixed metadata: the
+    # archive only changes when the data does.
+    n_set = 0
+    with tarfile.open(os.path.join(HERE, "freesasa_set.tar.xz"), "w:xz", preset=9) as tar:
+        for sub in ("freesasa_pdbs", "freesasa_reference"):
+            for name in sorted(os.listdir(os.path.join(REF, "tests/data", sub))):
+                data = open(os.path.join(REF, "tests/data", sub, name), "rb").read()
+                info = tarfile.TarInfo(f"{sub}/{name}")
+                info.size, info.mtime, info.mode = len(data), 0, 0o644
+                tar.addfile(info, io.BytesIO(data))
+                n_set += 1
+    print(f"wrote freesasa_set.tar.xz with {n_set} files")
 
     text = open(os.path.join(REF, "tests/common/data.rs")).read()
     m = re.search(r"FIXED_LOW_RES_ATOMS:\s*\[f32;\s*(\d+)\]\s*=\s*\[(.*?)\];", text, re.S)
