@@ -163,8 +163,9 @@ static bool bind_thread_to(pthread_t th, const NodeCpus &nc)
 }
 
 struct LatticeEntry {
-    float *d = nullptr;  // x | y | z, each `padded` floats, | (x, y, z, 0) records | patch table (16 bytes per patch)
+    float *d = nullptr;  // x | y | z, each `padded` floats, | (x, y, z, 0) records | patch table (16 bytes per patch) | mx_tab
     uint32_t padded = 0;
+    uint32_t mx_tab_at = 0;  // float offset of Lattice::mx_tab (0: none, more than 128 points)
     uint32_t n_patches = 0;  // 0: the points are in the reference's order and have no patch table
 };
 
@@ -489,7 +490,7 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
         // the cache holds the few point counts a program uses; a sweep over many counts must not
         // pin 28 bytes per point per count forever
         size_t cached_bytes = 0;
-        for (const auto &kv : ctx->lattices) cached_bytes += 7 * sizeof(float) * (size_t)kv.second.padded + 16 * (size_t)kv.second.n_patches;
+        for (const auto &kv : ctx->lattices) cached_bytes += 7 * sizeof(float) * (size_t)kv.second.padded + 16 * (size_t)kv.second.n_patches + 1536;
         if (ctx->lattices.size() >= 16 || cached_bytes > (64u << 20)) {
             RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (const Pending &pd : ctx->pending)
@@ -501,7 +502,8 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
         const uint32_t padded = (uint32_t)((n_points + 63) / 64 * 64);
         const uint32_t n_patches = n_points > 128 ? (uint32_t)((n_points + 15) / 16) : 0u;
         const uint32_t patches_padded = (n_patches + 63u) / 64u * 64u;
-        std::vector<float> h(7 * (size_t)padded + 4 * (size_t)patches_padded, 0.0f);  // x | y | z | (x, y, z, 0) records | patches
+        const uint32_t tab_at = 7 * padded + 4 * patches_padded;
+        std::vector<float> h((size_t)tab_at + mx_tab_floats((uint32_t)n_points), 0.0f);  // x | y | z | (x, y, z, 0) records | patches | mx_tab
         generate_sphere_points(n_points, h.data(), h.data() + padded, h.data() + 2 * (size_t)padded);
         if (n_patches) {
             // compact patches: permute the fused-rule points (see bisect_points), then one table entry per patch:
@@ -540,9 +542,22 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
             r4[1] = h[padded + i];
             r4[2] = h[2 * (size_t)padded + i];
         }
+        if (n_points <= 128) {
+            // the matrix-core kernel's operand tables (device_types.h mx_tab_floats)
+            const uint32_t np = 16u * mx_tab_tiles((uint32_t)n_points), nps = np + 16u;
+            float *t = h.data() + tab_at;
+            uint16_t *t16 = reinterpret_cast<uint16_t *>(t + 4 * (size_t)nps);
+            for (size_t i = 0; i < n_points; i++) {
+                const float px = h[i], py = h[padded + i], pz = h[2 * (size_t)padded + i];
+                t[i] = pz; t[nps + i] = py; t[2 * (size_t)nps + i] = px; t[3 * (size_t)nps + i] = -1.0f;
+                t16[4 * i] = f16_bits((_Float16)pz); t16[4 * i + 1] = f16_bits((_Float16)py);
+                t16[4 * i + 2] = f16_bits((_Float16)px); t16[4 * i + 3] = f16_bits((_Float16)-1.0f);
+            }
+        }
         LatticeEntry e;
         e.padded = padded;
         e.n_patches = n_patches;
+        e.mx_tab_at = n_points <= 128 ? tab_at : 0u;
         RS_HIP(ctx, hipMalloc((void **)&e.d, h.size() * sizeof(float)));
         hipError_t err = hipMemcpy(e.d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
         if (err != hipSuccess) {
@@ -557,6 +572,7 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
     out->xyz4 = (const float4 *)(it->second.d + 3 * (size_t)it->second.padded);
     out->patches = it->second.n_patches ? (const uint4 *)(it->second.d + 7 * (size_t)it->second.padded) : nullptr;
     out->n_patches = it->second.n_patches;
+    out->mx_tab = it->second.mx_tab_at ? it->second.d + it->second.mx_tab_at : nullptr;
     out->n_points = (uint32_t)n_points;
     out->n_fused = (uint32_t)(n_points - n_points % (size_t)ctx->simd_width);
     return RSASA_OK;
@@ -1210,7 +1226,7 @@ int run_small_host_batch(rsasa_context *ctx, const float *x, const float *y, con
             }
             mr = fmaxf(mr, radius[i]);
             finite &= std::isfinite(radius[i]);
-            odd_r |= !(radius[i] >= 0.0f && radius[i] <= 64.0f);
+            odd_r |= !(radius[i] >= 0.0f && radius[i] <= 64.0f) || !(fmaxf(fmaxf(fabsf(p[0]), fabsf(p[1])), fabsf(p[2])) <= 1e8f);
         }
         if (!finite || !small_grid(mn, mx, mr, probe, so[s + 1] - so[s], &grids[s])) return kNotSmall;
         grids[s].atom_begin = so[s];

@@ -21,8 +21,9 @@ struct StructGrid {
     uint32_t sorted_base;          // first position of the structure in the cell-sorted arrays
     uint32_t in_lds;               // 1: binned by k_sort_window (fewer than 65536 atoms; 16-bit cell starts relative
                                    // to sorted_base), 0: by the batch-wide kernels (32-bit absolute cell starts)
-    uint32_t odd_radii;            // bit 0: some radius of the structure lies outside [0, 64] or is NaN (the matrix-core
-                                   // occlusion kernel leaves such structures to the general kernel);
+    uint32_t odd_radii;            // bit 0: some radius of the structure lies outside [0, 64] or is NaN, or some coordinate is
+                                   // NaN, infinite or beyond 1e8 (the matrix-core occlusion kernel leaves such structures
+                                   // to the general kernel: its padding records must be finite vectors);
                                    // bits 8..9: log2 of the x-cell block its atom groups share (grid_group_shift)
 };
 static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
@@ -35,7 +36,7 @@ struct StructAcc {
     int max_r;
     uint32_t n_atoms;      // atoms of the structure (sum over its bounds workgroups)
     uint32_t first_atom;   // smallest atom index of the structure
-    int odd_radii;         // nonzero: a radius outside [0, 64] or NaN (see StructGrid::odd_radii)
+    int odd_radii;         // nonzero: a radius outside [0, 64] or NaN, a coordinate non-finite or beyond 1e8 (see StructGrid::odd_radii)
 };
 
 // A contiguous slice of one structure handled by one bounds workgroup.
@@ -70,11 +71,20 @@ struct Lattice {
     const float *x, *y, *z;  // device SoA, padded with zeros to a multiple of 64 entries
     const float4 *xyz4;      // the same points as (x, y, z, 0) records
     const uint4 *patches;    // point counts above 128: one entry per aligned run of 16 points, f16 (cz, cy | cx, -1 | eps, 0 | 0, 0)
+    const float *mx_tab;     // at most 128 points: the matrix-core kernel's operand tables (mx_tab_floats(): context.cpp get_lattice);
+                             // single-wave workgroups read them from here (L1 / L2 hits), not from a per-workgroup LDS copy
     uint32_t n_patches;      // (see context.cpp bisect_points, occlusion_mx.inc); else null / 0
     uint32_t n_points;
     uint32_t n_fused;        // points [0, n_fused) use the fused-FMA `<` rule (lib.rs:143-146);
                              // the rest the scalar remainder rule (lib.rs:185-186,206-207)
 };
+
+// Lattice::mx_tab (point counts up to 128): NT = 6, 7 or 8 tiles of 16 points cover them (the kernel's template
+// argument); NPS = 16 NT + 16.  Floats [0, 4 NPS): the points component major, (z | y | x | -1) x NPS, entries
+// behind the last point zero (among them the 16 behind the tiles: a column that nothing occludes); then 16 NT
+// entries of 8 bytes: the same points as f16 (z, y | x, -1), rounded to nearest, zero behind the last point.
+inline uint32_t mx_tab_tiles(uint32_t n_points) { return n_points <= 96u ? 6u : n_points <= 112u ? 7u : 8u; }
+inline uint32_t mx_tab_floats(uint32_t n_points) { return n_points > 128u ? 0u : 4u * (16u * mx_tab_tiles(n_points) + 16u) + 2u * 16u * mx_tab_tiles(n_points); }
 
 // Running sums of the grid placement scan: (cells, atoms) of the LDS-binned / tail structures.
 struct GridSums {

@@ -57,10 +57,10 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     float mnx = __int_as_float(0x7F800000), mny = mnx, mnz = mnx;
     float mxx = __int_as_float(0xFF800000), mxy = mxx, mxz = mxx;
     float mr = 0.0f;
-    bool odd_r = false;  // a radius outside [0, 64] (or NaN): see StructGrid::odd_radii
+    bool odd_r = false;  // a radius outside [0, 64] (or NaN), a coordinate beyond 1e8 (or NaN / infinite): see StructGrid::odd_radii
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
         float x = b.x[i], y = b.y[i], z = b.z[i], r = load_radius(b.radius, b.radius8, b.radius_table, i);
-        odd_r |= !(r >= 0.0f && r <= 64.0f);
+        odd_r |= !(r >= 0.0f && r <= 64.0f) | !(fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) <= 1e8f) | (x != x) | (y != y) | (z != z);
         mnx = fminf(mnx, x); mxx = fmaxf(mxx, x);
         mny = fminf(mny, y); mxy = fmaxf(mxy, y);
         mnz = fminf(mnz, z); mxz = fmaxf(mxz, z);

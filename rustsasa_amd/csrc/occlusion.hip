@@ -92,6 +92,14 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
     else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
 }
 
+// Waves per workgroup of k_occlusion_mx with at most 128 points.  4: the waves share an LDS copy of the point tables.
+// 1 (measured in round 5, kept as a build option): single-wave workgroups that read the tables from global memory
+// (Lattice::mx_tab) - a wave's LDS is free the moment it ends, wave-slot utilisation 90 -> 94 % (SQ_WAVE_CYCLES), but every
+// wave waits longer for its operands and the kernel's time is the same (3.497 against 3.473 ms): the kernel is bound by
+// its units, not by the waves in flight.
+#ifndef MX_NW
+#define MX_NW 4
+#endif
 constexpr uint32_t kMxLdsBudget = 157u * 1024u;  // what workgroups of k_occlusion_mx can share of a CU's 160 KB (see launch_occlusion)
 
 // static LDS of the many-point instantiations per wave (the same for every NW: the lists are per wave)
@@ -177,9 +185,12 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
             const bool has_id = b.id != nullptr;
             // (+ 16 zero entries of the f32 table: the column that pads phase B's last round)
-            if (lat.n_points <= 96u) launch_mx<6, false, 4>(has_id, rem, b.n_atoms, 24u * 96u + 256u, stream, a3);
-            else if (lat.n_points <= 112u) launch_mx<7, false, 4>(has_id, rem, b.n_atoms, 24u * 112u + 256u, stream, a3);
-            else if (lat.n_points <= 128u) launch_mx<8, false, 4>(has_id, rem, b.n_atoms, 24u * 128u + 256u, stream, a3);
+            // (-DMX_NW=1: single-wave workgroups, the tables read from Lattice::mx_tab, no dynamic LDS)
+            constexpr int kNW = MX_NW;
+            constexpr uint32_t kTabs = kNW == 1 ? 0u : 1u;
+            if (lat.n_points <= 96u) launch_mx<6, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 96u + 256u), stream, a3);
+            else if (lat.n_points <= 112u) launch_mx<7, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 112u + 256u), stream, a3);
+            else if (lat.n_points <= 128u) launch_mx<8, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 128u + 256u), stream, a3);
             else {
                 // More points: whole tiles of 16 points in the two tables, the patch table behind them (16 bytes per tile,
                 // whole blocks of 64, and a zero entry).  The tables are per workgroup, the lists per wave (3.4 KB): pick
