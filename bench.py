@@ -69,7 +69,18 @@ def parse_args(argv=None):
                    help="timed steps of the secondary 1M-atom / 960-point measurement (BASELINE.json configs[4]; 0 = skip)")
     p.add_argument("--files", type=int, default=1000,
                    help="files of the secondary directory-mode measurement (files on /dev/shm -> residue values; 0 = skip)")
+    p.add_argument("--per-call-seconds", type=float, default=1.0,
+                   help="seconds per leg of the secondary drop-in measurement: rsasa_calculate_sasa_internal once per "
+                        "structure from 1 and from 16 host threads (0 = skip)")
     p.add_argument("--no-ids", action="store_true", help="pass id = NULL (all atoms distinct)")
+    p.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                   help="process group of a multi-rank run: nccl (= RCCL, one rank per GPU) or gloo (barrier and the "
+                        "MAX / SUM on the host: lets several ranks share one GPU, which RCCL cannot - tests only)")
+    p.add_argument("--device", type=int, default=None,
+                   help="GPU of this rank (default: LOCAL_RANK); with --dist-backend gloo every rank may name the same one")
+    p.add_argument("--verify-shards", action="store_true",
+                   help="every rank compares its own shard's atoms and residues with the oracle and rank 0 prints the "
+                        "per-rank verdicts (small --structures counts: the oracle runs on the rank's whole shard)")
     p.add_argument("--dry-run", action="store_true",
                    help="CPU only (gloo): launcher, sharding and aggregation without any GPU work")
     return p.parse_args(argv)
@@ -447,6 +458,43 @@ def files_leg(n_files):
     return r
 
 
+def per_call_leg(batch, n_points, seconds):
+    """The literal drop-in path (reference src/lib.rs:249-254 called per file from every rayon
+    worker, src/main.rs:375,439): `rsasa_calculate_sasa_internal` - AoS atoms in, per-atom values out, host buffers -
+    once per structure, over the proteome's size mix (every 16th structure of the list), from 1 and from 16 host
+    threads with a context each.  A child process (rustsasa_amd/lib/bench_per_call): no interpreter between the calls."""
+    import tempfile
+    import numpy as np
+    import bench_workloads as bw
+    import rustsasa_amd
+    exe = os.path.join(ROOT, "rustsasa_amd", "lib", "bench_per_call")
+    if not os.path.exists(exe):
+        return {"error": "rustsasa_amd/lib/bench_per_call not built (make -C rustsasa_amd/csrc)"}
+    b = bw.select(batch, np.arange(0, batch.n_structures, 16))
+    atoms = rustsasa_amd.make_atoms(b.x, b.y, b.z, b.radius, b.ids)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    fd, path = tempfile.mkstemp(prefix="rsasa_per_call_", suffix=".bin", dir=base)
+    try:
+        with os.fdopen(fd, "wb") as f:
+            f.write(np.uint32(b.n_structures).tobytes())
+            f.write(b.structure_offsets.astype(np.uint32).tobytes())
+            f.write(atoms.tobytes())
+        p = subprocess.run([exe, path, str(n_points), str(seconds), "1", "16"], capture_output=True, text=True, timeout=300)
+        if p.returncode != 0:
+            return {"error": (p.stdout + p.stderr)[-300:]}
+        legs = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    finally:
+        os.unlink(path)
+    sizes = np.diff(b.structure_offsets.astype(np.int64))
+    return {"entry_point": "rsasa_calculate_sasa_internal (AoS rsasa_atom_t in, per-atom f32 out, pageable host buffers)",
+            "structures_in_rotation": b.n_structures, "atoms_per_structure_median": int(np.median(sizes)),
+            "atoms_per_structure_max": int(sizes.max()), "n_points": n_points,
+            "threads_1": next((x for x in legs if x.get("threads") == 1), None),
+            "threads_16": next((x for x in legs if x.get("threads") == 16), None),
+            "definition": "one structure per call, one context per host thread, all on this GPU; the threads draw "
+                          "structures from one shared counter for the leg's duration; every call timed (p50 / p99)"}
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -463,7 +511,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        if args.dry_run:
+        if args.dry_run or args.dist_backend == "gloo":
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
@@ -472,8 +520,12 @@ def main():
         world = dist.get_world_size()  # n_gpus is what RCCL says, not what --gpus asked for
     if args.dry_run:
         return dry_run(args, dist, rank, world)
+    if args.device is not None:
+        local_rank = args.device  # (gloo runs: ranks may share a GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the tensors the process group reduces: on the GPU for RCCL, on the host for gloo
+    red_dev = torch.device("cpu") if (dist and args.dist_backend == "gloo") else dev
     # NUMA: before any pinned allocation and before the library starts its threads
     all_cpus = os.sched_getaffinity(0)
     numa = numa_bind(gpu_pci_address(torch, local_rank))
@@ -555,12 +607,30 @@ def main():
 
     elapsed = timed(dist, 1, timed_region)
     ctx.enable_timing(False)
-    elapsed, total_structures, total_atoms = aggregate(dist, dev, elapsed, batch.n_structures,
+    elapsed, total_structures, total_atoms = aggregate(dist, red_dev, elapsed, batch.n_structures,
                                                        batch.n_atoms)
     got_atoms = run.outs[(args.steps - 1) % 2][0].cpu().numpy()
     got_res = run.outs[(args.steps - 1) % 2][1].cpu().numpy()
     outputs_equal = args.steps < 2 or bool(torch.equal(run.outs[0][1], run.outs[1][1]) and
                                              torch.equal(run.outs[0][0], run.outs[1][0]))
+
+    # ---- every rank's shard against the oracle (tests: the N > 1 path with the real engine on every rank) ----
+    shard_parity = None
+    if args.verify_shards:
+        from oracle import pyoracle as po
+        want = po.calculate_sasa_batch(batch.x, batch.y, batch.z, batch.radius, batch.ids, batch.structure_offsets,
+                                       PROBE, n_points, 8, threads=0)
+        want_res = po.residue_sums(want, batch.residue_offsets)
+        mine = {"rank": rank, "device": local_rank, "structures": batch.n_structures, "atoms": batch.n_atoms,
+                "shard_indices": [int(i) for i in getattr(batch, "shard_indices", np.arange(batch.n_structures))],
+                "atoms_equal_oracle": bool(np.array_equal(got_atoms, want)),
+                "residues_equal_oracle": bool(np.array_equal(got_res, want_res)),
+                "total_sasa": float(np.sum(got_atoms, dtype=np.float64))}
+        shard_parity = [None] * world
+        if dist:
+            dist.all_gather_object(shard_parity, mine)
+        else:
+            shard_parity = [mine]
 
     # ---- SURVEY 8d's definition: pinned host SoA in, per-residue values back on the host ----
     h2h = None
@@ -569,7 +639,7 @@ def main():
         for _ in range(3):
             h2h_step()
         h_el = timed(dist, args.h2h_steps, h2h_step)
-        h_el, h_structs, _ = aggregate(dist, dev, h_el, batch.n_structures, batch.n_atoms)
+        h_el, h_structs, _ = aggregate(dist, red_dev, h_el, batch.n_structures, batch.n_atoms)
         h2h = {"value": round(h_structs * args.h2h_steps / h_el, 2), "unit": "structures/s",
                "ms_per_step": round(h_el / args.h2h_steps * 1e3, 4), "steps": args.h2h_steps,
                "definition": "SURVEY 8d: pre-parsed SoA in pinned host memory -> per-residue values "
@@ -591,7 +661,7 @@ def main():
 
         t_el = timed(dist, args.two_steps, seq_step)
         ctx.enable_timing(False)
-        t_el, t_structs, _ = aggregate(dist, dev, t_el, batch.n_structures, batch.n_atoms)
+        t_el, t_structs, _ = aggregate(dist, red_dev, t_el, batch.n_structures, batch.n_atoms)
         two = {"value": round(t_structs * args.two_steps / t_el, 2), "unit": "structures/s",
                "ms_per_step": round(t_el / args.two_steps * 1e3, 4), "steps": args.two_steps,
                "occlusion_kernel_ms": round(float(np.mean(seq_occl)), 4),
@@ -607,7 +677,7 @@ def main():
         for _ in range(2):
             wrun.step()
         w_el = timed(dist, args.weak_steps, wrun.step)
-        w_el, w_structs, _ = aggregate(dist, dev, w_el, wb.n_structures, wb.n_atoms)
+        w_el, w_structs, _ = aggregate(dist, red_dev, w_el, wb.n_structures, wb.n_atoms)
         weak = {"value": round(w_structs * args.weak_steps / w_el, 2), "unit": "structures/s",
                 "ms_per_step": round(w_el / args.weak_steps * 1e3, 4), "steps": args.weak_steps,
                 "structures_per_gpu": wb.n_structures}
@@ -621,6 +691,11 @@ def main():
     files_mode = None
     if rank == 0 and world == 1 and args.workload == "proteome" and args.files > 0 and not shard_of:
         files_mode = files_leg(args.files)
+
+    # ---- secondary (rank 0, one GPU): the drop-in call per structure, from 1 and 16 host threads ----
+    per_call = None
+    if rank == 0 and world == 1 and args.workload == "proteome" and args.per_call_seconds > 0 and not shard_of:
+        per_call = per_call_leg(batch, n_points, args.per_call_seconds)
 
     if config5:
         pmcu, _ = load_pmc("pmc_uniform1m.json")
@@ -713,10 +788,18 @@ def main():
             line["config5"] = config5
         if files_mode:
             line["files_mode"] = files_mode
+        if per_call:
+            line["per_call"] = per_call
         if two:
             line["one_at_a_time"] = two
         if shard_of:
             line["config"]["shard_of"] = shard_of
+        if shard_parity:
+            all_idx = sorted(i for sp in shard_parity for i in sp["shard_indices"])
+            line["shard_parity"] = [{k: v for k, v in sp.items() if k != "shard_indices"} for sp in shard_parity]
+            line["shards_disjoint_and_complete"] = (all_idx == list(range(int(total_structures)))
+                                                    if scaling == "strong" else None)
+            line["config"]["dist_backend"] = args.dist_backend if dist else None
         if weak:
             line["weak_scaling"] = weak
         if args.cpu_seconds > 0:  # (rank 0, on its own shard at N > 1)

@@ -1,6 +1,7 @@
 """Re-entrancy of the C ABI on the GPU: the reference's hot path is called concurrently from
 rayon workers in directory mode (src/main.rs:375), so the drop-in must give the same answers
 when driven from several host threads -- one context per thread, or one shared context."""
+import os
 import threading
 
 import numpy as np
@@ -8,6 +9,8 @@ import pytest
 
 import bench_workloads as bw
 from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -131,3 +134,33 @@ def test_two_batches_in_flight_in_one_context():
     # the oracle on one of the batches, so that "equal" is not equally wrong
     b = batches[2]
     assert np.array_equal(want[2][0], po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, 1.4, 100, 8, threads=4))
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu():
+    """The N > 1 path with the REAL engine on every rank (reference src/main.rs:375,439: files dealt to workers that
+    run the hot path by themselves): `bench.py --gpus 2` starts its two ranks itself, the strong-scaling sharder gives
+    each its structures, each rank runs the timed stepping on its shard and compares it with the oracle.  RCCL cannot
+    put two ranks on one device, and the test boxes have one: the process group is gloo (barrier, MAX / SUM on the host)
+    and both ranks name device 0.  No scaling number is read off this."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+                        "--device", "0", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--h2h-steps", "0",
+                        "--two-steps", "0", "--config5-steps", "0", "--files", "0", "--per-call-seconds", "0", "--weak-steps", "0",
+                        "--structures", "96", "--verify-shards"], capture_output=True, text=True, env=env,
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 3
+    assert out["config"]["dist_backend"] == "gloo" and out["config"]["structures_total"] == 96
+    assert out["shards_disjoint_and_complete"] is True
+    sp = out["shard_parity"]
+    assert [s["rank"] for s in sp] == [0, 1] and all(s["device"] == 0 for s in sp)
+    assert sum(s["structures"] for s in sp) == 96 and all(s["atoms"] >= 32768 for s in sp)  # (the matrix-core kernel's batches)
+    assert all(s["atoms_equal_oracle"] and s["residues_equal_oracle"] for s in sp), sp
+    assert out["config"]["outputs_of_both_workspaces_equal"] is True

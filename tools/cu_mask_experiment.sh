@@ -4,7 +4,7 @@
 # the others: does hiding the grid build behind the occlusion kernel pay for the CUs that kernel loses?  
 out=gpurun_out/cu_mask.txt
 : > $out
-args="--steps 40 --warmup 5 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0"
+args="--steps 40 --warmup 5 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0"
 run() {  # label, env assignments..., -- bench args
     label=$1; shift
     line=$(env "$@" python3 bench.py $args $EXTRA 2>/dev/null | tail -1)
