@@ -549,6 +549,9 @@ def main():
                       None if args.no_ids else pin(batch.ids), pin(batch.residue_offsets),
                       pin(np.zeros(batch.n_residues, np.float32)),
                       pin(np.zeros(batch.n_atoms, np.float32)) if want_atoms else None)
+        # a second set of outputs: two host batches are in flight in the stream leg
+        h2h_out2 = (pin(np.zeros(batch.n_residues, np.float32)),
+                    pin(np.zeros(batch.n_atoms, np.float32)) if want_atoms else None)
     ctx = rustsasa_amd.Context(local_rank)
 
     def h2h_step():
@@ -556,9 +559,25 @@ def main():
         ctx.calculate_sasa_batch(hx, hy, hz, hr, hid, batch.structure_offsets, PROBE, n_points,
                                  residue_offsets=hro, want_atoms=hatm is not None, atom_out=hatm, res_out=hres)
 
+    def h2h_enqueue(k):
+        hx, hy, hz, hr, hid, hro, hres, hatm = h2h_arrays
+        res, atm = (hres, hatm) if k % 2 == 0 else h2h_out2
+        ctx.host_batch_enqueue(hx, hy, hz, hr, hid, batch.structure_offsets, PROBE, n_points,
+                               residue_offsets=hro, want_atoms=atm is not None, atom_out=atm, res_out=res)
+
+    def h2h_stream(steps):
+        """`steps` host batches as a rank of a sharded run works through them: batch k + 1 is enqueued before batch k
+        is waited for (rsasa_host_batch_enqueue / _wait)."""
+        h2h_enqueue(0)
+        for k in range(1, steps):
+            h2h_enqueue(k)
+            ctx.host_batch_wait()
+        ctx.host_batch_wait()
+
     if h2h_arrays:
         for _ in range(3):
             h2h_step()
+        h2h_stream(4)  # (the stream's two worker contexts allocate their workspaces and staging here)
     stream = None  # the context's own launch streams (one per batch in flight); its HIP events time the kernels on them
     run = DeviceRun(ctx, batch, n_points, dev, not args.no_ids, stream)
 
@@ -638,14 +657,26 @@ def main():
         hres = h2h_arrays[6]
         for _ in range(3):
             h2h_step()
-        h_el = timed(dist, args.h2h_steps, h2h_step)
+        s_el = timed(dist, args.h2h_steps, h2h_step)   # one synchronous call after the other
+        s_el, _, _ = aggregate(dist, red_dev, s_el, batch.n_structures, batch.n_atoms)
+        sync_equal = bool(np.array_equal(hres, got_res))
+        hres[:] = 0.0
+        h2h_out2[0][:] = 0.0
+        h2h_stream(4)
+        n_stream = max(2, args.h2h_steps)
+        h_el = timed(dist, 1, lambda: h2h_stream(n_stream))
         h_el, h_structs, _ = aggregate(dist, red_dev, h_el, batch.n_structures, batch.n_atoms)
-        h2h = {"value": round(h_structs * args.h2h_steps / h_el, 2), "unit": "structures/s",
-               "ms_per_step": round(h_el / args.h2h_steps * 1e3, 4), "steps": args.h2h_steps,
-               "definition": "SURVEY 8d: pre-parsed SoA in pinned host memory -> per-residue values "
-                             "in pinned host memory (H2D, all kernels, D2H), sub-batches pipelined "
-                             "over a copy-in, a compute and a copy-out stream",
-               "residues_equal_hbm_run": bool(np.array_equal(hres, got_res))}
+        h2h = {"value": round(h_structs * n_stream / h_el, 2), "unit": "structures/s",
+               "ms_per_step": round(h_el / n_stream * 1e3, 4), "steps": n_stream,
+               "definition": "SURVEY 8d: pre-parsed SoA in pinned host memory -> per-residue values in pinned host "
+                             "memory (H2D, all kernels, D2H), as a STREAM of host batches: batch k + 1 enqueued before "
+                             "batch k is waited for (rsasa_host_batch_enqueue / _wait; a batch's sub-batches pipelined "
+                             "over a copy-in, a compute and a copy-out stream, the calls taking turns on the link)",
+               "residues_equal_hbm_run": bool(sync_equal and np.array_equal(hres, got_res)
+                                              and np.array_equal(h2h_out2[0], got_res)),
+               "one_call_at_a_time": {"ms_per_step": round(s_el / args.h2h_steps * 1e3, 4),
+                                      "value": round(h_structs * args.h2h_steps / s_el, 2),
+                                      "definition": "rsasa_calculate_sasa_batch, each call waited for before the next"}}
 
     # ---- secondary: one batch at a time (enqueue, wait, enqueue, ...): what a caller with a single batch sees ----
     two = None

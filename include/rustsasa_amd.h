@@ -29,8 +29,10 @@ extern "C" {
 #endif
 
 /* 2: rsasa_batch_wait returns the OLDEST of up to two batches in flight (version 1 had one batch in flight, so
- * "the" batch); rsasa_batch_wait_all, rsasa_context_get_simd_width, rsasa_context_bind_thread added. */
-#define RSASA_ABI_VERSION 2
+ * "the" batch); rsasa_batch_wait_all, rsasa_context_get_simd_width, rsasa_context_bind_thread added.
+ * 3: rsasa_host_batch_enqueue / _wait / _wait_all (a stream of host batches), rsasa_context_clone_settings added;
+ * nothing changed or removed. */
+#define RSASA_ABI_VERSION 3
 
 typedef enum rsasa_status {
     RSASA_OK = 0,
@@ -87,6 +89,12 @@ int rsasa_context_get_simd_width(rsasa_context_t *ctx, int *out_simd_width);
  * node, hides its topology, or RSASA_NUMA=0 is set; then nothing is bound. */
 int rsasa_context_bind_thread(rsasa_context_t *ctx, int *out_numa_node);
 
+/* Copies every setting that changes how `src` computes - the pulp lane count
+ * and the kernel tuning a process may have set - to `dst`: for programs that
+ * run several contexts side by side (a second context on the same GPU, one
+ * context per GPU) and want them to give the same values. */
+int rsasa_context_clone_settings(rsasa_context_t *dst, rsasa_context_t *src);
+
 /* ---- the hot path, one structure per call ------------------------------ */
 
 /* Drop-in for calculate_sasa_internal (reference src/lib.rs:249-254).
@@ -124,6 +132,34 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                                float probe_radius, size_t n_points, float *out_atom_sasa,
                                const uint32_t *residue_offsets, size_t n_residues,
                                float *out_residue_sasa);
+
+/* A STREAM of host batches (ABI 3): the same arguments and the same results as
+ * rsasa_calculate_sasa_batch, but the call returns once the batch is queued.  A
+ * rank that works through its share of a directory (reference
+ * src/main.rs:375: files dealt to workers) enqueues batch k + 1 before it
+ * waits for batch k: batch k + 1's first atoms cross the link while batch k's
+ * last sub-batches compute and download, which one synchronous call after the
+ * other cannot do (its first upload hides behind nothing, and nothing hides
+ * its last kernels).  Two batches compute at a time - on two private contexts
+ * on the caller's GPU, created by the first call (their workspaces and pinned
+ * staging are sized like the caller's own would be, and live until
+ * rsasa_context_destroy) - with the caller's settings at the time of the
+ * enqueue; up to eight may be queued and not yet waited for.
+ * rsasa_host_batch_wait() returns the OLDEST enqueued batch: it blocks until
+ * that batch is complete and returns its status (the message is then the
+ * context's last error); with nothing enqueued it returns RSASA_OK at once.
+ * Every buffer of a batch - inputs and outputs - belongs to the library from
+ * the enqueue until the wait that returns the batch.  Pinned (page-locked)
+ * host memory makes all copies asynchronous, as for the synchronous call. */
+int rsasa_host_batch_enqueue(rsasa_context_t *ctx, const float *x, const float *y,
+                             const float *z, const float *radius, const uint64_t *id,
+                             const uint32_t *structure_offsets, size_t n_structures,
+                             float probe_radius, size_t n_points, float *out_atom_sasa,
+                             const uint32_t *residue_offsets, size_t n_residues,
+                             float *out_residue_sasa);
+int rsasa_host_batch_wait(rsasa_context_t *ctx);
+/* Waits for every enqueued host batch, oldest first; returns the first error. */
+int rsasa_host_batch_wait_all(rsasa_context_t *ctx);
 
 /* Device-resident form of the batch call: every pointer in the descriptor is
  * a DEVICE pointer on the context's GPU except structure_offsets_host, which

@@ -218,6 +218,12 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
                                                           FilesTimings *timings);
 }  // namespace detail
 
+// SASAOptions::process_files keeps a second context per GPU for the life of the process (its HBM workspaces, pinned
+// staging and coding threads: a fresh one per call cost more than a call's second chunk).  They are released when the
+// process ends normally; a long-lived program that is done with directory mode calls this to get them back at once
+// (contexts a running process_files call is using stay).
+void release_cached_contexts();
+
 template <typename Level>
 class SASAOptions {
 public:

@@ -82,6 +82,11 @@ SYMBOLS = {
     "rsasa_batch_enqueue": (C.c_int, [_vp, C.POINTER(DeviceBatch), C.c_float, C.c_size_t, _vp]),
     "rsasa_batch_wait": (C.c_int, [_vp]),
     "rsasa_batch_wait_all": (C.c_int, [_vp]),
+    "rsasa_host_batch_enqueue": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t,
+                                           C.c_float, C.c_size_t, _vp, _vp, C.c_size_t, _vp]),
+    "rsasa_host_batch_wait": (C.c_int, [_vp]),
+    "rsasa_host_batch_wait_all": (C.c_int, [_vp]),
+    "rsasa_context_clone_settings": (C.c_int, [_vp, _vp]),
     "rsasa_context_enable_timing": (C.c_int, [_vp, C.c_int]),
     "rsasa_context_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
     "rsasa_sphere_points": (C.c_int, [C.c_size_t, _vp, _vp, _vp]),

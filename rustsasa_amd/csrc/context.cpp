@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <new>
@@ -305,6 +306,39 @@ private:
     bool quit = false;
 };
 
+// rsasa_host_batch_enqueue / _wait: a stream of host batches on one context handle.  Two worker threads, each with a
+// private context on the caller's GPU, run rsasa_calculate_sasa_batch on the queued batches in order; the link turn
+// (LinkTurn, below) lets the second call's uploads follow the first one's.  Results are handed back oldest first.
+struct HostStream {
+    struct Job {
+        const float *x, *y, *z, *radius;
+        const uint64_t *id;
+        const uint32_t *structure_offsets;
+        size_t n_structures;
+        float probe;
+        size_t n_points;
+        float *out_atom;
+        const uint32_t *residue_offsets;
+        size_t n_residues;
+        float *out_res;
+        // the caller's settings at the enqueue (the worker's context takes them before it computes)
+        int simd_width = 8;
+        bool small_path = true, overlap_tail = false;
+        OcclusionTuning tuning;
+        int rc = 0;
+        std::string error;
+        bool taken = false, done = false;
+    };
+    static constexpr int kWorkers = 2;
+    static constexpr size_t kMaxQueued = 8;  // enqueued and not yet waited for (a further enqueue waits for the oldest to complete)
+    rsasa_context *sub[kWorkers] = {nullptr, nullptr};
+    std::thread th[kWorkers];
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<std::shared_ptr<Job>> jobs;  // oldest first; entries leave in rsasa_host_batch_wait
+    bool quit = false;
+};
+
 }  // namespace rsasa
 
 using namespace rsasa;
@@ -353,20 +387,24 @@ struct rsasa_context {
                  &sorted_id32 = ws[0].sorted_id32, &status = ws[0].status, &atom_sasa = ws[0].atom_sasa, &claim = ws[0].claim;
     // staging for the host-pointer entry points (device)
     DeviceBuffer in_x, in_y, in_z, in_r, in_id, in_res, out_res, out_k;
-    // further input / output slots of the pipelined host-buffer path (kSlots sub-batches in flight)
-    DeviceBuffer in2_x, in2_y, in2_z, in2_r, in2_id, in2_res, in3_x, in3_y, in3_z, in3_r, in3_id, in3_res;
-    DeviceBuffer atom_sasa2, out_res2, atom_sasa3, out_res3;
+    // Further input / output slots of the pipelined host-buffer path: a slot per sub-batch of a call (kSlots >= the
+    // most sub-batches a call is cut into), so the uploads never wait for a slot - they follow each other at the
+    // link's rate however far the kernels are behind, and in a stream of host batches (rsasa_host_batch_enqueue) the
+    // next call's first upload follows this call's last one while this call's kernels are still running.  With three
+    // slots the link idled at every call boundary until the new call's first sub-batch had been computed (5.3 ms per
+    // proteome batch in a stream, no better than one call after the other).
+    static constexpr int kSlots = 8;
+    struct MoreSlot { DeviceBuffer x, y, z, r, id, res, atom_sasa, out_res; } more[kSlots - 1];
     // Pipelined host path: everything of a sub-batch that the host prepares - radius table, rebased residue offsets,
     // folded ids, radius codes - sits in ONE pinned block per sub-batch and crosses the link in ONE copy (every
     // copy costs the link about 12 us of idle time).
-    DeviceBuffer in_pack[3];                      // that block of the sub-batch in slot k, on the device
+    DeviceBuffer in_pack[kSlots];                 // that block of the sub-batch in slot k, on the device
     char *h_pack = nullptr;                       // pinned: the blocks of a whole host batch
     size_t h_pack_cap = 0;
     FoldPool *fold_pool = nullptr;                // created by the first large (pipelined) host call
     RadiusCodec radius_codec;
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
     hipStream_t d2h_stream = nullptr;             // D2H of the previous sub-batch's results meanwhile
-    static constexpr int kSlots = 3;
     hipEvent_t ev_copy[kSlots] = {};
     hipEvent_t ev_d2h[kSlots] = {};               // output slot k has been copied out
     void *h_out[kSlots] = {};                     // pinned staging for results whose destination is pageable
@@ -393,6 +431,8 @@ struct rsasa_context {
     Pending pending[2];   // device batches in flight, oldest first: pending[head], pending[head ^ 1]
     int head = 0, n_pending = 0;
     OcclusionTuning tuning;
+    hipEvent_t ev_link = nullptr;  // recorded behind the last upload of a pipelined host call (LinkTurn)
+    struct HostStream *host_stream = nullptr;  // rsasa_host_batch_enqueue / _wait: two workers with a context each
 };
 
 namespace {
@@ -443,6 +483,63 @@ struct DeviceGuard {
                                                          : RSASA_ERR_HIP,           \
                         #expr, e_);                                                 \
     } while (0)
+
+// ---- one upload phase at a time per device ----------------------------------------------------------------------
+// A pipelined host call is bound by the link and by the kernels at once; its first sub-batch's upload hides behind
+// nothing and nothing hides its last sub-batches' kernels.  A STREAM of host batches - two contexts on one GPU, each
+// with a call in flight (rsasa_host_batch_enqueue does exactly that) - hides both, provided the calls take turns on the
+// link: two calls uploading at the same time share its 52 GB/s and each other's copy gaps, and both finish later than
+// one after the other would (two contexts without turns: 5.9 ms per proteome batch against 5.2 for one).  The turn is
+// taken before a call queues its first upload and passed on behind its last one: the next call's copy stream waits for
+// that upload's event, its first sub-batch then crosses the link while the previous call's last ones compute.
+struct LinkTurn {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool busy = false;
+    hipEvent_t last = nullptr;            // behind the previous holder's last upload, on its copy stream
+    const rsasa_context *owner = nullptr;  // the context `last` belongs to (cleared when it is destroyed)
+};
+LinkTurn g_link[64];
+
+struct LinkHold {
+    LinkTurn *lt = nullptr;
+    rsasa_context *ctx = nullptr;
+    bool held = false;
+    // waits for the turn; the caller's copy stream then waits for the previous holder's last upload
+    hipError_t take(rsasa_context *c, hipStream_t cp)
+    {
+        if (c->device < 0 || c->device >= 64) return hipSuccess;
+        lt = &g_link[c->device];
+        ctx = c;
+        hipEvent_t prev = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(lt->mu);
+            lt->cv.wait(lk, [&] { return !lt->busy; });
+            lt->busy = true;
+            held = true;
+            if (lt->owner != c) prev = lt->last;
+        }
+        return prev ? hipStreamWaitEvent(cp, prev, 0) : hipSuccess;
+    }
+    // every upload of the call has been queued on `cp`
+    void pass(hipStream_t cp)
+    {
+        if (!held) return;
+        const bool ok = ctx->ev_link && hipEventRecord(ctx->ev_link, cp) == hipSuccess;
+        std::lock_guard<std::mutex> lk(lt->mu);
+        if (ok) { lt->last = ctx->ev_link; lt->owner = ctx; }
+        lt->busy = false;
+        held = false;
+        lt->cv.notify_one();
+    }
+    ~LinkHold()
+    {
+        if (!held) return;  // (an error return: nothing to order behind)
+        std::lock_guard<std::mutex> lk(lt->mu);
+        lt->busy = false;
+        lt->cv.notify_one();
+    }
+};
 
 // Grows `b` to at least `bytes` (contents are NOT preserved).  The caller has
 // already drained the stream if the buffer may be in use.
@@ -929,6 +1026,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_link, hipEventDisableTiming);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming);
     for (int i = 0; i < rsasa_context::kSlots && e == hipSuccess; i++) {
@@ -954,6 +1052,20 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
 int rsasa_context_destroy(rsasa_context_t *ctx)
 {
     if (!ctx) return RSASA_OK;
+    if (HostStream *hs = ctx->host_stream) {
+        // queued host batches finish (their buffers are the caller's: it has been told to wait for them), then the workers go
+        {
+            std::unique_lock<std::mutex> lk(hs->mu);
+            hs->cv_done.wait(lk, [&] { for (auto &j : hs->jobs) if (!j->done) return false; return true; });
+            hs->quit = true;
+        }
+        hs->cv_work.notify_all();
+        for (auto &t : hs->th)
+            if (t.joinable()) t.join();
+        for (rsasa_context *sc : hs->sub) rsasa_context_destroy(sc);
+        delete hs;
+        ctx->host_stream = nullptr;
+    }
     DeviceGuard guard(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
@@ -962,12 +1074,12 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
                             &ctx->rank_of, &ctx->cells, &ctx->windows, &ctx->scan_sums, &ctx->sorted_xyzr,
                             &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa, &ctx->claim,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
-                            &ctx->in2_x, &ctx->in2_y, &ctx->in2_z, &ctx->in2_r, &ctx->in2_id, &ctx->in2_res,
-                            &ctx->in3_x, &ctx->in3_y, &ctx->in3_z, &ctx->in3_r, &ctx->in3_id, &ctx->in3_res,
-                            &ctx->atom_sasa2, &ctx->out_res2, &ctx->atom_sasa3, &ctx->out_res3,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
-                            &ctx->tr_id, &ctx->tr_res, &ctx->in_pack[0], &ctx->in_pack[1], &ctx->in_pack[2]})
+                            &ctx->tr_id, &ctx->tr_res})
         release(*b);
+    for (DeviceBuffer &b : ctx->in_pack) release(b);
+    for (auto &m : ctx->more)
+        for (DeviceBuffer *b : {&m.x, &m.y, &m.z, &m.r, &m.id, &m.res, &m.atom_sasa, &m.out_res}) release(*b);
     delete ctx->fold_pool;
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     for (auto &kv : ctx->lattices)
@@ -1005,6 +1117,11 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->device >= 0 && ctx->device < 64) {
+        std::lock_guard<std::mutex> lk(g_link[ctx->device].mu);
+        if (g_link[ctx->device].owner == ctx) { g_link[ctx->device].last = nullptr; g_link[ctx->device].owner = nullptr; }
+    }
+    if (ctx->ev_link) (void)hipEventDestroy(ctx->ev_link);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1381,9 +1498,13 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     static const bool h2h_trace = std::getenv("RSASA_H2H_TRACE") != nullptr;  // host-side phases of a pipelined call, to stderr
     const auto tr_t0 = std::chrono::steady_clock::now();
     auto tr = [&](const char *what) {
-        if (h2h_trace)
-            std::fprintf(stderr, "h2h %8.1f us  %s\n",
-                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr_t0).count(), what);
+        if (h2h_trace) {
+            static const auto epoch = std::chrono::steady_clock::now();  // (calls of several contexts on one clock)
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "h2h ctx %p at %9.1f us, %8.1f us into the call: %s\n", (void *)ctx,
+                         std::chrono::duration<double, std::micro>(now - epoch).count(),
+                         std::chrono::duration<double, std::micro>(now - tr_t0).count(), what);
+        }
     };
     if (ctx->n_pending && (rc = wait_pending(ctx))) return rc;
     if (ctx->small_path) {
@@ -1437,12 +1558,13 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     const size_t n_sub = cut.size() - 1;
     constexpr size_t kTableWords = 256;  // a sub-batch's offsets block on the device: radius table | residue offsets
     constexpr int kSlots = rsasa_context::kSlots;
-    const int n_slots = piped ? kSlots : 1;
-    DeviceBuffer *bx[kSlots] = {&ctx->in_x, &ctx->in2_x, &ctx->in3_x}, *by[kSlots] = {&ctx->in_y, &ctx->in2_y, &ctx->in3_y};
-    DeviceBuffer *bz[kSlots] = {&ctx->in_z, &ctx->in2_z, &ctx->in3_z}, *br[kSlots] = {&ctx->in_r, &ctx->in2_r, &ctx->in3_r};
-    DeviceBuffer *bi[kSlots] = {&ctx->in_id, &ctx->in2_id, &ctx->in3_id}, *bo[kSlots] = {&ctx->in_res, &ctx->in2_res, &ctx->in3_res};
-    DeviceBuffer *oa[kSlots] = {&ctx->atom_sasa, &ctx->atom_sasa2, &ctx->atom_sasa3};
-    DeviceBuffer *orr[kSlots] = {&ctx->out_res, &ctx->out_res2, &ctx->out_res3};
+    const int n_slots = piped ? (int)std::min<size_t>((size_t)kSlots, n_sub) : 1;
+    DeviceBuffer *bx[kSlots] = {&ctx->in_x}, *by[kSlots] = {&ctx->in_y}, *bz[kSlots] = {&ctx->in_z}, *br[kSlots] = {&ctx->in_r};
+    DeviceBuffer *bi[kSlots] = {&ctx->in_id}, *bo[kSlots] = {&ctx->in_res}, *oa[kSlots] = {&ctx->atom_sasa}, *orr[kSlots] = {&ctx->out_res};
+    for (int k = 1; k < kSlots; k++) {
+        rsasa_context::MoreSlot &m = ctx->more[k - 1];
+        bx[k] = &m.x; by[k] = &m.y; bz[k] = &m.z; br[k] = &m.r; bi[k] = &m.id; bo[k] = &m.res; oa[k] = &m.atom_sasa; orr[k] = &m.out_res;
+    }
     const float *dev_x[kSlots] = {}, *dev_y[kSlots] = {}, *dev_z[kSlots] = {};
     for (int k = 0; k < n_slots; k++) {
         if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
@@ -1701,6 +1823,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     for (int attempt = 0;; attempt++) {
         uint64_t need_cells = 0;
         int err = RSASA_OK;
+        LinkHold turn;  // (released without an event on an error return)
         auto check = [&](int k) {  // status of the sub-batch that used host slot k (its event has been waited for)
             const BatchStatus stt = *ctx->slot[k].h_status;
             if (stt.grid_too_large && !err)
@@ -1725,6 +1848,9 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             fold_drain.pool = ctx->fold_pool;
             fold_drain.last = fold_job[n_sub - 1];
         }
+        // (the coding jobs above run while this call waits for its turn on the link)
+        RS_HIP(ctx, turn.take(ctx, cp));
+        tr("turn on the link taken");
         for (size_t c = 0; c < n_sub; c++) {
             const int k = (int)(c % kSlots);
             if (used[k]) {
@@ -1777,6 +1903,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             used[k] = true;
             if (h2h_trace) tr(c + 1 == n_sub ? "last sub-batch enqueued" : "sub-batch enqueued");
         }
+        turn.pass(cp);  // the next call's uploads follow this one's last
+        tr("turn passed on");
         for (int k = 0; k < kSlots; k++) {
             if (!used[k]) continue;
             RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
@@ -1790,6 +1918,153 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if (need_cells >= 0xFFFFFFF0ull || attempt >= 3)
             return fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "batch needs more than 2^32 grid cells; split it");
         ctx->cell_capacity = need_cells + need_cells / 8 + 1024;
+    }
+}
+
+// ---- a stream of host batches (ABI 3) ----
+
+int rsasa_context_clone_settings(rsasa_context_t *dst, rsasa_context_t *src)
+{
+    int rc = resolve_ctx(src);
+    if (rc) return rc;
+    if (!dst || dst == src) return dst ? RSASA_OK : RSASA_ERR_INVALID_ARGUMENT;
+    int simd = 8;
+    bool small = true, overlap = false;
+    OcclusionTuning tune;
+    {
+        std::lock_guard<std::recursive_mutex> lk(src->mu);
+        simd = src->simd_width; small = src->small_path; overlap = src->overlap_tail; tune = src->tuning;
+    }
+    std::lock_guard<std::recursive_mutex> lk(dst->mu);
+    dst->simd_width = simd; dst->small_path = small; dst->overlap_tail = overlap; dst->tuning = tune;
+    return RSASA_OK;
+}
+
+static void host_stream_worker(HostStream *hs, int w)
+{
+    (void)rsasa_context_bind_thread(hs->sub[w], nullptr);
+    for (;;) {
+        std::shared_ptr<HostStream::Job> job;
+        {
+            std::unique_lock<std::mutex> lk(hs->mu);
+            hs->cv_work.wait(lk, [&] {
+                if (hs->quit) return true;
+                for (auto &j : hs->jobs) if (!j->taken) return true;
+                return false;
+            });
+            for (auto &j : hs->jobs)
+                if (!j->taken) { job = j; break; }  // oldest first
+            if (!job) return;                        // quit and nothing left to take
+            job->taken = true;
+        }
+        {
+            std::lock_guard<std::recursive_mutex> lk(hs->sub[w]->mu);
+            hs->sub[w]->simd_width = job->simd_width;
+            hs->sub[w]->small_path = job->small_path;
+            hs->sub[w]->overlap_tail = job->overlap_tail;
+            hs->sub[w]->tuning = job->tuning;
+        }
+        const int rc = rsasa_calculate_sasa_batch(hs->sub[w], job->x, job->y, job->z, job->radius, job->id, job->structure_offsets,
+                                                  job->n_structures, job->probe, job->n_points, job->out_atom,
+                                                  job->residue_offsets, job->n_residues, job->out_res);
+        std::string msg = rc ? rsasa_context_last_error(hs->sub[w]) : "";
+        {
+            std::lock_guard<std::mutex> lk(hs->mu);
+            job->rc = rc;
+            job->error = std::move(msg);
+            job->done = true;
+        }
+        hs->cv_done.notify_all();
+    }
+}
+
+int rsasa_host_batch_enqueue(rsasa_context_t *ctx, const float *x, const float *y, const float *z,
+                             const float *radius, const uint64_t *id, const uint32_t *structure_offsets,
+                             size_t n_structures, float probe_radius, size_t n_points, float *out_atom_sasa,
+                             const uint32_t *residue_offsets, size_t n_residues, float *out_residue_sasa)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    HostStream *hs = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        if (!ctx->host_stream) {
+            hs = new (std::nothrow) HostStream();
+            if (!hs) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "host stream");
+            for (int w = 0; w < HostStream::kWorkers; w++) {
+                rc = rsasa_context_create(ctx->device, &hs->sub[w]);
+                if (rc) {
+                    for (rsasa_context *sc : hs->sub) rsasa_context_destroy(sc);
+                    delete hs;
+                    return fail(ctx, rc, "rsasa_context_create (host stream worker)");
+                }
+            }
+            for (int w = 0; w < HostStream::kWorkers; w++) hs->th[w] = std::thread(host_stream_worker, hs, w);
+            ctx->host_stream = hs;
+        }
+        hs = ctx->host_stream;
+    }
+    auto job = std::make_shared<HostStream::Job>();
+    {
+        // the workers compute with the caller's settings as they are now (lane count, kernel choice); the worker that
+        // takes the job applies them (its context is locked for the length of the call it is in)
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        job->simd_width = ctx->simd_width; job->small_path = ctx->small_path; job->overlap_tail = ctx->overlap_tail;
+        job->tuning = ctx->tuning;
+    }
+    job->x = x; job->y = y; job->z = z; job->radius = radius; job->id = id;
+    job->structure_offsets = structure_offsets; job->n_structures = n_structures;
+    job->probe = probe_radius; job->n_points = n_points; job->out_atom = out_atom_sasa;
+    job->residue_offsets = residue_offsets; job->n_residues = n_residues; job->out_res = out_residue_sasa;
+    {
+        std::unique_lock<std::mutex> lk(hs->mu);
+        // (a full queue: wait until its oldest batch has been computed - its status stays queued for rsasa_host_batch_wait)
+        hs->cv_done.wait(lk, [&] { return hs->jobs.size() < HostStream::kMaxQueued || hs->jobs.front()->done; });
+        if (hs->jobs.size() >= HostStream::kMaxQueued)
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "too many host batches enqueued and not waited for (rsasa_host_batch_wait)");
+        hs->jobs.push_back(job);
+    }
+    hs->cv_work.notify_all();
+    return RSASA_OK;
+}
+
+int rsasa_host_batch_wait(rsasa_context_t *ctx)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    HostStream *hs = nullptr;
+    {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        hs = ctx->host_stream;
+    }
+    if (!hs) return RSASA_OK;  // nothing was ever enqueued
+    std::shared_ptr<HostStream::Job> job;
+    {
+        std::unique_lock<std::mutex> lk(hs->mu);
+        if (hs->jobs.empty()) return RSASA_OK;
+        job = hs->jobs.front();
+        hs->cv_done.wait(lk, [&] { return job->done; });
+        hs->jobs.pop_front();
+    }
+    hs->cv_done.notify_all();  // (an enqueue may be waiting for room)
+    if (job->rc) return fail(ctx, job->rc, job->error.c_str());
+    return RSASA_OK;
+}
+
+int rsasa_host_batch_wait_all(rsasa_context_t *ctx)
+{
+    int first = RSASA_OK;
+    for (;;) {
+        {
+            int rc = resolve_ctx(ctx);
+            if (rc) return rc;
+            std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+            if (!ctx->host_stream) return first;
+            std::lock_guard<std::mutex> lk2(ctx->host_stream->mu);
+            if (ctx->host_stream->jobs.empty()) return first;
+        }
+        const int rc = rsasa_host_batch_wait(ctx);
+        if (rc && !first) first = rc;
     }
 }
 

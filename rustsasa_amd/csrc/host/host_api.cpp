@@ -1765,6 +1765,33 @@ std::vector<Result<typename Level::Output>> process_many(const std::vector<const
     return out;
 }
 
+// process_files' cached second context per device (see there)
+struct Companion {
+    rsasa_context_t *ctx = nullptr;
+    bool busy = false;
+};
+static std::mutex &companions_mutex()
+{
+    static std::mutex *m = new std::mutex();  // (never destroyed: the atexit handler below may run after other statics)
+    return *m;
+}
+static std::map<int, Companion> &companions_map()
+{
+    static std::map<int, Companion> *m = new std::map<int, Companion>();
+    return *m;
+}
+void release_cached_contexts_impl()
+{
+    std::lock_guard<std::mutex> lk(companions_mutex());
+    auto &m = companions_map();
+    for (auto it = m.begin(); it != m.end();) {
+        if (it->second.busy) { ++it; continue; }  // (a process_files call is running with it)
+        if (it->second.ctx) rsasa_context_destroy(it->second.ctx);
+        it = m.erase(it);
+    }
+}
+static void release_cached_contexts() { release_cached_contexts_impl(); }
+
 // Directory mode at library level (reference src/main.rs:342-480 without the CLI): files are
 // parsed and filtered on `host_threads` threads, then each chunk of `files_per_batch` structures
 // is ONE GPU batch.
@@ -1804,12 +1831,14 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // threads: creating one per call cost more than the call's second chunk); a call that finds it taken creates its
     // own.  It runs with the caller's context's settings: the pulp lane count decides which points take the remainder
     // rule, and chunks go to whichever worker is free.
-    struct Companion {
-        rsasa_context_t *ctx = nullptr;
-        bool busy = false;
-    };
-    static std::mutex companions_mu;
-    static std::map<int, Companion> companions;
+    // The cached companions are released when the process ends normally, BEFORE the HIP runtime's own static teardown
+    // (atexit handlers registered later run earlier; this one is registered after the first context exists, i.e. after
+    // the runtime started up); rustsasa::release_cached_contexts() does the same on request - a long-lived host program
+    // that is done with directory mode gets its HBM workspaces, pinned staging and coding threads back.
+    static std::mutex &companions_mu = companions_mutex();
+    static std::map<int, Companion> &companions = companions_map();
+    static const bool registered = (std::atexit([] { release_cached_contexts(); }), true);
+    (void)registered;
     struct Borrowed {
         rsasa_context_t *ctx = nullptr;
         int device = -1;
@@ -1841,9 +1870,8 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
             }
         }
         if (!second.ctx && rsasa_context_create(device, &second.ctx) != RSASA_OK) second.ctx = nullptr;
-        int simd_width = 8;
-        if (second.ctx && rsasa_context_get_simd_width(contexts[0], &simd_width) == RSASA_OK &&
-            rsasa_context_set_simd_width(second.ctx, simd_width) == RSASA_OK)
+        // (every setting that changes how the caller's context computes: lane count, kernel tuning)
+        if (second.ctx && rsasa_context_clone_settings(second.ctx, contexts[0]) == RSASA_OK)
             contexts.push_back(second.ctx);
         else
             contexts.push_back(contexts[0]);  // (no second context: two workers share the one)
@@ -2018,6 +2046,8 @@ RSASA_INSTANTIATE(ProteinLevel)
 #undef RSASA_INSTANTIATE
 
 }  // namespace detail
+
+void release_cached_contexts() { detail::release_cached_contexts_impl(); }
 
 Result<SelectedAtoms> select_atoms_by_chain(const Structure &pdb, const OptionValues &o)
 {

@@ -77,11 +77,13 @@ class Context:
         if simd_width != 8:
             self.set_simd_width(simd_width)
         self._keepalive = []  # buffers of the batches in flight, oldest first
+        self._host_keepalive = []  # the same for host batches (host_batch_enqueue)
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.rsasa_context_destroy(self._h)
+            self._lib.rsasa_context_destroy(self._h)  # (waits for queued host batches)
             self._h = None
+            self._host_keepalive = []
 
     def __del__(self):
         try:
@@ -143,6 +145,44 @@ class Context:
             self._h, ptr(x), ptr(y), ptr(z), ptr(radius), ptr(ids), ptr(so), n_struct,
             probe_radius, n_points, ptr(atom_out), ptr(ro), n_res, ptr(res_out)))
         return atom_out, res_out
+
+    # ---- a stream of host batches ------------------------------------------
+    def host_batch_enqueue(self, x, y, z, radius, ids, structure_offsets,
+                           probe_radius: float = 1.4, n_points: int = 100,
+                           residue_offsets=None, want_atoms: bool = True, atom_out=None,
+                           res_out=None):
+        """rsasa_host_batch_enqueue: as calculate_sasa_batch, but returns once the batch is queued; the results are
+        in (atom_out, res_out) - returned here - after the host_batch_wait() that returns this batch.  All arrays
+        are kept alive until then; do not touch them in between."""
+        so = _offsets("structure_offsets", structure_offsets)
+        n_struct = so.shape[0] - 1
+        x, y, z, radius, ids = _columns(x, y, z, radius, ids, int(so[-1]) if n_struct else 0)
+        atom_out = _out_buffer("atom_out", atom_out, x.shape[0]) if want_atoms else None
+        ro = None
+        n_res = 0
+        if residue_offsets is not None:
+            ro = _offsets("residue_offsets", residue_offsets)
+            n_res = ro.shape[0] - 1
+            res_out = _out_buffer("res_out", res_out, n_res)
+        else:
+            res_out = None
+        self._check(self._lib.rsasa_host_batch_enqueue(
+            self._h, ptr(x), ptr(y), ptr(z), ptr(radius), ptr(ids), ptr(so), n_struct,
+            probe_radius, n_points, ptr(atom_out), ptr(ro), n_res, ptr(res_out)))
+        self._host_keepalive.append((x, y, z, radius, ids, so, ro, atom_out, res_out))
+        return atom_out, res_out
+
+    def host_batch_wait(self):
+        """Waits for the oldest enqueued host batch and raises its error, if any."""
+        try:
+            self._check(self._lib.rsasa_host_batch_wait(self._h))
+        finally:
+            if self._host_keepalive:
+                self._host_keepalive.pop(0)
+
+    def host_batch_wait_all(self):
+        while self._host_keepalive:
+            self.host_batch_wait()
 
     # ---- MD trajectory: one topology, many frames --------------------------
     def calculate_sasa_trajectory(self, xyz, radius, ids=None, probe_radius: float = 1.4,

@@ -164,3 +164,69 @@ def test_two_ranks_share_one_gpu():
     assert sum(s["structures"] for s in sp) == 96 and all(s["atoms"] >= 32768 for s in sp)  # (the matrix-core kernel's batches)
     assert all(s["atoms_equal_oracle"] and s["residues_equal_oracle"] for s in sp), sp
     assert out["config"]["outputs_of_both_workspaces_equal"] is True
+
+
+def test_stream_of_host_batches_matches_the_oracle(monkeypatch):
+    """rsasa_host_batch_enqueue / _wait (ABI 3): host batches enqueued ahead of the waits - two computing at a time,
+    their uploads taking turns on the link - give the oracle's values, in order, atoms and residues; a batch with bad
+    arguments reports through ITS wait and leaves the stream usable; pageable and pinned outputs both work."""
+    import torch
+    import rustsasa_amd
+    monkeypatch.setenv("RSASA_SUB_ATOMS", "100000")  # sub-batches (the pipelined path) from 200 k atoms on, not 3 M
+    batches = [bw.synthetic_proteome(n, seed=s) for n, s in ((120, 11), (90, 12), (150, 13), (70, 14), (110, 15))]
+    assert all(b.n_atoms >= 200000 for b in batches[:3])
+    want = [po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+            for b in batches]
+
+    def pin(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
+
+    with rustsasa_amd.Context(0) as ctx:
+        assert ctx._lib.rsasa_host_batch_wait(ctx._h) == 0  # nothing enqueued: returns at once
+        outs = []
+
+        def enq(k, pinned):
+            b = batches[k]
+            cols = [b.x, b.y, b.z, b.radius, b.ids, b.residue_offsets]
+            if pinned:
+                cols = [pin(c) for c in cols]
+            x, y, z, r, ids, ro = cols
+            outs.append(ctx.host_batch_enqueue(x, y, z, r, ids, b.structure_offsets, PROBE, 100, residue_offsets=ro,
+                                               atom_out=pin(np.zeros(b.n_atoms, np.float32)) if pinned else None,
+                                               res_out=pin(np.zeros(b.n_residues, np.float32)) if pinned else None))
+
+        enq(0, True); enq(1, False); enq(2, True)      # three queued: two compute, one waits for a worker
+        ctx.host_batch_wait()                          # batch 0
+        enq(3, False); enq(4, True)
+        # a batch with decreasing residue offsets: rejected when a worker takes it, reported by the wait that returns it
+        b = batches[3]
+        bad_ro = b.residue_offsets.copy()
+        bad_ro[3], bad_ro[4] = bad_ro[4] + 5, bad_ro[3]
+        ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, residue_offsets=bad_ro)
+        for _ in range(4):
+            ctx.host_batch_wait()                      # batches 1 .. 4
+        with pytest.raises(rustsasa_amd.RsasaError):
+            ctx.host_batch_wait()                      # the bad one
+        enq(1, True)                                   # the stream goes on
+        ctx.host_batch_wait_all()
+        for k, (atom, res) in zip([0, 1, 2, 3, 4, 1], outs):
+            assert np.array_equal(atom, want[k]), k
+            assert np.array_equal(res, po.residue_sums(want[k], batches[k].residue_offsets)), k
+        # the context itself still serves synchronous calls with the same settings
+        b = batches[3]
+        atom, _ = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100)
+        assert np.array_equal(atom, want[3])
+
+
+def test_stream_of_host_batches_runs_with_the_callers_lane_count():
+    """The stream's worker contexts take the caller's settings at every enqueue (rsasa_context_clone_settings): with
+    pulp's lane count 16, 100 points have four remainder points, and the values must be that lane count's."""
+    import rustsasa_amd
+    b = bw.synthetic_proteome(30, seed=21)
+    with rustsasa_amd.Context(0) as ctx:
+        for w in (16, 8):
+            ctx.set_simd_width(w)
+            atom, _ = ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100)
+            ctx.host_batch_wait()
+            want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, w, threads=0)
+            assert np.array_equal(atom, want), w
