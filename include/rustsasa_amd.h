@@ -97,6 +97,21 @@ int rsasa_context_clone_settings(rsasa_context_t *dst, rsasa_context_t *src);
 
 /* ---- the hot path, one structure per call ------------------------------ */
 
+/* Non-finite input (every entry point of the hot path, every kernel).
+ * The reference checks nothing; what its arithmetic does with a NaN is
+ * reproduced bit for bit: a NaN coordinate is skipped by the bounding box
+ * (f32::min / max, spatial_grid.rs:113-121), lands in cell 0 (`as u32`,
+ * :139-141) and fails every distance test (:321-335), so the atom is nobody's
+ * neighbour, has no neighbours and keeps its whole sphere; a NaN radius makes
+ * that atom's own value NaN (src/lib.rs:101-102,220-222) and is skipped by the
+ * maximum radius (lib.rs:262).  Other atoms and the other structures of a
+ * batch are not affected.  An INFINITE coordinate overflows the reference's
+ * grid arithmetic (it panics): here the call - for a batch: the whole batch,
+ * whose grids are placed by one scan - returns RSASA_ERR_GRID_TOO_LARGE and
+ * the context stays usable.  probe_radius + largest radius not a positive
+ * finite number - an infinite radius among them: an infinite cell size,
+ * lib.rs:76 - returns RSASA_ERR_INVALID_ARGUMENT. */
+
 /* Drop-in for calculate_sasa_internal (reference src/lib.rs:249-254).
  * `threads` is accepted for signature compatibility and ignored (the
  * reference uses it only to choose sequential vs rayon, src/lib.rs:278).

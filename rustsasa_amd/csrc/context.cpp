@@ -1282,7 +1282,7 @@ bool small_grid(const float mn_in[3], const float mx_in[3], float max_r, float p
 {
     const float cell = probe + max_r;  // lib.rs:76
     const float inv = 1.0f / cell;     // spatial_grid.rs:36
-    if (!(cell > 0.0f) || !(inv < INFINITY)) return false;
+    if (!(cell > 0.0f) || !(inv < INFINITY) || !(cell < INFINITY)) return false;
     StructGrid g{};
     unsigned long long nc = 1;
     uint32_t d[3];

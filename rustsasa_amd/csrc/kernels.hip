@@ -117,8 +117,13 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
         nc = 1; d[0] = d[1] = d[2] = 1;
         mn[0] = mn[1] = mn[2] = 0.0f;
         inv = 1.0f; cell = 1.0f;
-    } else if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000))) { bad = true; nc = 1; d[0] = d[1] = d[2] = 1; }
-    if (nc > 0x7FFFFFFFull) { too_large = true; nc = 1; d[0] = d[1] = d[2] = 1; }
+    } else if (!(cell > 0.0f) || !(inv < __int_as_float(0x7F800000)) || !(cell < __int_as_float(0x7F800000))) {
+        // (probe + largest radius zero, negative, NaN - or infinite: a cell size the culling arithmetic cannot work with)
+        bad = true; nc = 1; d[0] = d[1] = d[2] = 1;
+    }
+    // (an infinite coordinate saturates an extent and the + 1 wraps it to 0 - where the reference's u32 arithmetic
+    // panics: the structure's grid is "too large" too)
+    if (nc > 0x7FFFFFFFull || (a.n_atoms != 0 && (d[0] == 0u || d[1] == 0u || d[2] == 0u))) { too_large = true; nc = 1; d[0] = d[1] = d[2] = 1; }
     g.min_x = mn[0]; g.min_y = mn[1]; g.min_z = mn[2];
     g.inv_cell = inv;
     g.dim_x = d[0]; g.dim_y = d[1]; g.dim_z = d[2];

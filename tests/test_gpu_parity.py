@@ -1039,3 +1039,86 @@ def test_duplicate_ids_in_device_batches():
         atom, _, _ = _device_run(c, bb, want_res=False)
         want = po.calculate_sasa_batch(b.x, b.y, b.z, r2, bb.ids, b.structure_offsets, PROBE, 100, 8, threads=8)
         assert np.array_equal(atom, want)
+
+
+# ---- non-finite input (include/rustsasa_amd.h, "Non-finite input") ----------------------------------------------
+# The reference has no checks: NaN coordinates fall out of its arithmetic (f32::min / max skip them in the bounds,
+# `as u32` sends them to cell 0, every distance to them is NaN and fails every comparison: spatial_grid.rs:113-121,
+# 139-141, 321-335), a NaN radius makes that atom's own value NaN (lib.rs:101-102,220-222); an infinite coordinate or
+# radius overflows its grid arithmetic (a panic).  Here: NaN behaves as in the oracle, bit for bit, on every entry
+# point and kernel, without touching the other atoms or structures of a batch; infinities are the call's error.
+
+def _poison(b, where):
+    x, y, z, r = b.x.copy(), b.y.copy(), b.z.copy(), b.radius.copy()
+    so = b.structure_offsets
+    neg_nan = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
+    if "coords" in where:
+        x[so[3] + 5] = np.nan            # structure 3: two atoms with NaN coordinates, one of them a negative NaN
+        y[so[3] + 40] = neg_nan
+        z[so[3] + 40] = np.nan
+    if "radius" in where:
+        r[so[7] + 11] = np.nan           # structure 7: a NaN radius
+    if "all" in where:
+        x[so[9]:so[10]] = np.nan         # structure 9: every atom without a position
+    return bw.Batch(x, y, z, r, b.ids, b.structure_offsets, b.residue_offsets)
+
+
+@pytest.mark.parametrize("where", ["coords", "radius", "coords+radius+all"])
+@pytest.mark.parametrize("kernel", [None, "5", "3"])
+def test_nan_input_matches_the_oracle_and_leaves_the_neighbours_alone(where, kernel, monkeypatch):
+    import rustsasa_amd
+    if kernel:
+        monkeypatch.setenv("RSASA_OCCLUSION_KERNEL", kernel)
+    clean = bw.synthetic_proteome(40, seed=17)
+    b = _poison(clean, where)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+    want_clean = po.calculate_sasa_batch(clean.x, clean.y, clean.z, clean.radius, clean.ids, clean.structure_offsets,
+                                         PROBE, 100, 8, threads=0)
+    touched = {3} if where == "coords" else {7} if where == "radius" else {3, 7, 9}
+    so = b.structure_offsets
+    for s in range(b.n_structures):   # the oracle itself: other structures do not notice
+        if s not in touched:
+            assert np.array_equal(want[so[s]:so[s + 1]], want_clean[so[s]:so[s + 1]])
+    with rustsasa_amd.Context(0) as c:
+        atom, res, _ = _device_run(c, b, want_k=False)                       # device-resident batch
+        assert np.array_equal(atom, want, equal_nan=True)
+        assert np.array_equal(res, po.residue_sums(want, b.residue_offsets), equal_nan=True)
+        atom_h, res_h = c.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                               residue_offsets=b.residue_offsets)   # host batch
+        assert np.array_equal(atom_h, want, equal_nan=True) and np.array_equal(res_h, res, equal_nan=True)
+        for s in sorted(touched):                                            # one structure per call
+            sl = slice(so[s], so[s + 1])
+            got = c.calculate_sasa_soa(b.x[sl], b.y[sl], b.z[sl], b.radius[sl], b.ids[sl], PROBE, 100)
+            assert np.array_equal(got, want[sl], equal_nan=True), s
+
+
+def test_infinite_input_is_the_calls_error_and_the_context_lives_on(ctx, example_vdw):
+    import rustsasa_amd
+    from rustsasa_amd import _capi
+    x, y, z, r, ids = example_vdw
+    want = po.calculate_sasa_internal(x, y, z, r, ids, PROBE, 100, 8)
+    for col in (0, 1, 2):
+        for v in (np.inf, -np.inf):
+            cols = [x.copy(), y.copy(), z.copy(), r.copy()]
+            cols[col][17] = v
+            with pytest.raises(rustsasa_amd.RsasaError) as e:
+                ctx.calculate_sasa_soa(*cols, ids, PROBE, 100)
+            assert e.value.status == _capi.RSASA_ERR_GRID_TOO_LARGE, (col, v, e.value)
+            assert np.array_equal(ctx.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100), want)
+    # an infinite radius makes the cell size infinite (lib.rs:76): invalid input, like probe + largest radius <= 0
+    r_inf = r.copy()
+    r_inf[17] = np.inf
+    with pytest.raises(rustsasa_amd.RsasaError) as e:
+        ctx.calculate_sasa_soa(x, y, z, r_inf, ids, PROBE, 100)
+    assert e.value.status == _capi.RSASA_ERR_INVALID_ARGUMENT
+    assert np.array_equal(ctx.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100), want)
+    # in a batch the error is the batch's (the grids of all its structures are placed by one scan)
+    b = bw.synthetic_proteome(40, seed=17)
+    xb = b.x.copy()
+    xb[b.structure_offsets[2] + 1] = np.inf
+    bad = bw.Batch(xb, b.y, b.z, b.radius, b.ids, b.structure_offsets, b.residue_offsets)
+    with pytest.raises(rustsasa_amd.RsasaError) as e:
+        _device_run(ctx, bad, want_k=False)
+    assert e.value.status == _capi.RSASA_ERR_GRID_TOO_LARGE
+    atom, _, _ = _device_run(ctx, b, want_k=False)
+    assert np.array_equal(atom, po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0))

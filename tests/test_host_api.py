@@ -775,3 +775,28 @@ def test_altloc_fixtures_meet_the_quality_gate_without_a_gpu():
             theirs.append(want[k])
     rmse = float(np.sqrt(np.mean((np.array(ours) - np.array(theirs)) ** 2)))
     assert len(ours) >= 7 and rmse <= RMSE_GATE, rmse
+
+
+@pytest.mark.gpu
+def test_process_files_with_nan_coordinates_in_one_file(tmp_path):
+    """`nan` in a coordinate column parses to NaN (as a Rust `parse::<f64>()` would give): that atom is nobody's
+    neighbour and keeps its whole sphere, the other atoms of the file and the other files of the batch do not notice
+    (include/rustsasa_amd.h, "Non-finite input")."""
+    src = open(sio.data_path("1jcd.pdb")).read().splitlines(keepends=True)
+    k = [i for i, l in enumerate(src) if l.startswith("ATOM")][25]
+    src[k] = src[k][:30] + "     nan" + src[k][38:]
+    bad = tmp_path / "nan_atom.pdb"
+    bad.write_text("".join(src))
+    paths = [sio.data_path("151L_H3.pdb"), str(bad), sio.data_path("example.cif")]
+    lst = str(tmp_path / "files.txt")
+    open(lst, "w").write("\n".join(paths) + "\n")
+    p = subprocess.run([CLI, "files", "residue", lst, "--full"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:500]
+    got = json.loads(p.stdout)
+    assert got["n_ok"] == 3
+    for path, r in zip(paths, got["results"]):
+        _, res, _ = expected(None, path=path)
+        assert np.array_equal(np.array(r, np.float32), res), path
+    atom, _, _ = expected(None, path=str(bad))
+    clean, _, _ = expected("1jcd.pdb")
+    assert np.sum(atom != clean) >= 1 and np.all(np.isfinite(atom))
