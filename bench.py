@@ -526,15 +526,25 @@ def main():
     dev = torch.device("cuda", local_rank)
     # the tensors the process group reduces: on the GPU for RCCL, on the host for gloo
     red_dev = torch.device("cpu") if (dist and args.dist_backend == "gloo") else dev
-    # NUMA: before any pinned allocation and before the library starts its threads
-    all_cpus = os.sched_getaffinity(0)
-    numa = numa_bind(gpu_pci_address(torch, local_rank))
-
-    import rustsasa_amd
     scaling = args.scaling if args.workload == "proteome" else "weak"
     shard_of = args.shard_of if (world == 1 and args.workload == "proteome" and scaling == "strong") else 0
     batch, n_points, name = make_workload(args.workload, args.structures, args.n_points, rank, world,
                                           scaling, shard_of)
+    # The CPU baseline (rank 0) runs FIRST, before this process binds itself to its GPU's NUMA node: its OpenMP worker
+    # threads are created here, with the whole machine's affinity mask, and keep it (sched_setaffinity below changes the
+    # calling thread and the threads it starts afterwards, not the ones that exist).  Its values are kept for the parity
+    # diff of the timed run's output.
+    cpu_base = None
+    if rank == 0 and args.cpu_seconds > 0:
+        affinity_cpus = len(os.sched_getaffinity(0))
+        cpu_line, cmp_idx, cpu_want = cpu_baseline(batch, n_points, args.cpu_seconds)
+        cpu_line["affinity_cpus"] = affinity_cpus
+        cpu_line["ran"] = "before the GPU legs and before the NUMA binding of this process"
+        cpu_base = (cpu_line, cmp_idx, cpu_want)
+    # NUMA: before any pinned allocation and before the library starts its threads
+    numa = numa_bind(gpu_pci_address(torch, local_rank))
+
+    import rustsasa_amd
     # The host-to-host leg's pinned arrays and its first calls (which allocate the library's staging and sub-batch
     # buffers) come first (round 3 saw 6.2-6.7 instead of 5.8 ms per batch when they were allocated after the gigabytes
     # of the device-resident run; with the process bound to the GPU's NUMA node - numa_bind above - placement no
@@ -833,9 +843,8 @@ def main():
             line["config"]["dist_backend"] = args.dist_backend if dist else None
         if weak:
             line["weak_scaling"] = weak
-        if args.cpu_seconds > 0:  # (rank 0, on its own shard at N > 1)
-            os.sched_setaffinity(0, all_cpus)  # the CPU baseline gets every core (its threads are created in there)
-            line["cpu_baseline"], cmp_idx, want = cpu_baseline(batch, n_points, args.cpu_seconds)
+        if cpu_base:  # (rank 0, on its own shard at N > 1)
+            line["cpu_baseline"], cmp_idx, want = cpu_base
             line["parity"] = parity(batch, cmp_idx, want, got_atoms, got_res)
         print(json.dumps(line, default=lambda o: o.item() if hasattr(o, "item") else str(o)), flush=True)
 

@@ -30,6 +30,15 @@
 
 namespace rsasa {
 
+// The library's measurement switches (kernel choice, sub-batch sizes, copy experiments: INTEGRATION.md 7) are read only
+// when the process sets RSASA_TUNING=1: a production program's numerics path does not depend on stray environment
+// variables.  (RSASA_NUMA=0, which only says where threads may run, is read regardless.)
+const char *tuning_env(const char *name)
+{
+    static const bool on = [] { const char *v = std::getenv("RSASA_TUNING"); return v && std::atoi(v) != 0; }();
+    return on ? std::getenv(name) : nullptr;
+}
+
 // Golden-section spiral (reference src/lib.rs:43-66, constants
 // src/utils/consts.rs:18-19), f32 at every step, libm transcendentals.
 // Computed on the host and uploaded: the occlusion decision is integer valued,
@@ -379,7 +388,7 @@ struct rsasa_context {
     uint32_t grid_cus = 0, cu_mask_words = 0;
     uint32_t cu_reserved[16] = {}, cu_rest[16] = {};
     hipStream_t grid_stream = nullptr;
-    hipEvent_t ev_grid[2] = {nullptr, nullptr};
+    hipEvent_t ev_grid[2] = {nullptr, nullptr}, ev_grid_in[2] = {nullptr, nullptr};
     DeviceBuffer &segments = ws[0].segments, &acc = ws[0].acc, &grids = ws[0].grids, &grid_sums = ws[0].grid_sums,
                  &sid_sorted = ws[0].sid_sorted, &deferred_list = ws[0].deferred_list, &cell_of = ws[0].cell_of,
                  &rank_of = ws[0].rank_of, &cells = ws[0].cells, &windows = ws[0].windows, &scan_sums = ws[0].scan_sums,
@@ -552,6 +561,9 @@ int reserve(rsasa_context *ctx, DeviceBuffer &b, size_t bytes)
         RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->stream2) RS_HIP(ctx, hipStreamSynchronize(ctx->stream2));
         if (ctx->side_stream) RS_HIP(ctx, hipStreamSynchronize(ctx->side_stream));
+        if (ctx->copy_stream) RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (ctx->d2h_stream) RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
+        if (ctx->grid_stream) RS_HIP(ctx, hipStreamSynchronize(ctx->grid_stream));
         for (const Pending &pd : ctx->pending)
             if (pd.active && pd.stream && pd.stream != ctx->stream && pd.stream != ctx->stream2) RS_HIP(ctx, hipStreamSynchronize(pd.stream));
         RS_HIP(ctx, hipFree(b.p));
@@ -805,12 +817,18 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     // (RSASA_GRID_CUS experiment: the grid build on the stream of the reserved CUs, the rest behind an event)
     const bool masked = ctx->grid_stream && (pd.stream == ctx->stream || pd.stream == ctx->stream2) && !(ctx->overlap_tail && has_tail);
     hipStream_t gst = masked ? ctx->grid_stream : st;
+    if (masked) {
+        // the grid stream starts behind everything this batch has queued on its launch stream so far: the upload of the
+        // segments above and, on the pipelined host path, the wait for the sub-batch's input copies
+        RS_HIP(ctx, hipEventRecord(ctx->ev_grid_in[pd.ws], st));
+        RS_HIP(ctx, hipStreamWaitEvent(gst, ctx->ev_grid_in[pd.ws], 0));
+    }
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[0], gst));
     launch_grid_prepare(v, gst);
     // Two batches in flight: this one's grid build is enqueued beside the other one's occlusion kernel (it gets the CUs
     // when that kernel's workgroups retire: the kernel leaves a CU no room), its occlusion kernel behind it.
     rsasa_context::Workspace &other = ctx->ws[pd.ws ^ 1];
-    const bool chain = other.occ_recorded && !std::getenv("RSASA_FREE_OVERLAP");
+    const bool chain = other.occ_recorded && !tuning_env("RSASA_FREE_OVERLAP");
     const bool overlap = ctx->overlap_tail && has_tail;
     if (overlap && (rc = ensure_side_stream(ctx))) return rc;
     if (overlap) {
@@ -873,6 +891,7 @@ int wait_one(rsasa_context *ctx, Pending &pd)
                         "probe_radius + max radius must be a positive finite number");
         }
         if (!stt.overflow) {
+            ctx->tuning.deferred_hint = stt.deferred;  // (sizes the next batch's launch over its deferred list)
             if (ctx->timing) {
                 float g = 0, o = 0, a = 0, t = 0;
                 (void)hipEventElapsedTime(&g, W.ev[0], W.ev[1]);
@@ -986,12 +1005,12 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     ctx->node = device_node_cpus(device);
     DeviceGuard guard(device);
     hipError_t e = guard.err;
-    if (const char *v = std::getenv("RSASA_GRID_CUS")) {
+    if (const char *v = tuning_env("RSASA_GRID_CUS")) {
         int n_cu = 0;
         if (e == hipSuccess && hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n_cu > 0 && n_cu <= 512) {
             const int want = std::atoi(v);
             int stride = 1;  // RSASA_GRID_CU_STRIDE: reserved CUs are mask bits 0, stride, 2 stride, ...
-            if (const char *sv = std::getenv("RSASA_GRID_CU_STRIDE")) stride = std::max(1, std::atoi(sv));
+            if (const char *sv = tuning_env("RSASA_GRID_CU_STRIDE")) stride = std::max(1, std::atoi(sv));
             if (want > 0 && want * stride <= n_cu && want < n_cu) {
                 ctx->grid_cus = (uint32_t)want;
                 ctx->cu_mask_words = (uint32_t)(n_cu + 31) / 32;
@@ -1009,15 +1028,17 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
         if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->stream2, ctx->cu_mask_words, ctx->cu_rest);
         if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&ctx->grid_stream, ctx->cu_mask_words, ctx->cu_reserved);
         for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid[w], hipEventDisableTiming);
+        for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid_in[w], hipEventDisableTiming);
     } else if (e == hipSuccess) {
         e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
         // Experiment (RSASA_GRID_PRIO=1): the grid builds on a stream of the highest priority, so that their workgroups -
         // shaped to fit the slot an occlusion workgroup leaves - are dispatched ahead of the other batch's
-        if (e == hipSuccess && std::getenv("RSASA_GRID_PRIO")) {
+        if (e == hipSuccess && tuning_env("RSASA_GRID_PRIO")) {
             int least = 0, greatest = 0;
             e = hipDeviceGetStreamPriorityRange(&least, &greatest);
             if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->grid_stream, hipStreamNonBlocking, greatest);
             for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid[w], hipEventDisableTiming);
+            for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid_in[w], hipEventDisableTiming);
         }
     }
     for (int w = 0; w < rsasa_context::kInFlight; w++) {
@@ -1038,13 +1059,13 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
         rsasa_context_destroy(ctx);
         return RSASA_ERR_HIP;
     }
-    if (const char *v = std::getenv("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
-    if (const char *v = std::getenv("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
+    if (const char *v = tuning_env("RSASA_OCCLUSION_KERNEL")) ctx->tuning.kernel_version = std::atoi(v);
+    if (const char *v = tuning_env("RSASA_ATOMS_PER_WAVE")) ctx->tuning.atoms_per_wave = (uint32_t)std::atoi(v);
 #ifdef RSASA_ABLATE  // timing-ablation builds only (make ablate): the shipped library has no wrong-results switch
-    if (const char *v = std::getenv("RSASA_DEBUG_STOP")) ctx->tuning.debug_stop = (uint32_t)std::atoi(v);
+    if (const char *v = tuning_env("RSASA_DEBUG_STOP")) ctx->tuning.debug_stop = (uint32_t)std::atoi(v);
 #endif
-    if (const char *v = std::getenv("RSASA_OVERLAP_TAIL")) ctx->overlap_tail = std::atoi(v) != 0;
-    if (const char *v = std::getenv("RSASA_SMALL_PATH")) ctx->small_path = std::atoi(v) != 0;
+    if (const char *v = tuning_env("RSASA_OVERLAP_TAIL")) ctx->overlap_tail = std::atoi(v) != 0;
+    if (const char *v = tuning_env("RSASA_SMALL_PATH")) ctx->small_path = std::atoi(v) != 0;
     *out_ctx = ctx;
     return RSASA_OK;
 }
@@ -1105,6 +1126,8 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->grid_stream) (void)hipStreamDestroy(ctx->grid_stream);
     for (hipEvent_t ev : ctx->ev_grid)
+        if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->ev_grid_in)
         if (ev) (void)hipEventDestroy(ev);
     for (int i = 0; i < rsasa_context::kSlots; i++)
         if (ctx->ev_copy[i]) (void)hipEventDestroy(ctx->ev_copy[i]);
@@ -1495,7 +1518,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
-    static const bool h2h_trace = std::getenv("RSASA_H2H_TRACE") != nullptr;  // host-side phases of a pipelined call, to stderr
+    static const bool h2h_trace = tuning_env("RSASA_H2H_TRACE") != nullptr;  // host-side phases of a pipelined call, to stderr
     const auto tr_t0 = std::chrono::steady_clock::now();
     auto tr = [&](const char *what) {
         if (h2h_trace) {
@@ -1519,15 +1542,15 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     // host-to-device copies run on a second stream into a second set of input buffers while the
     // previous sub-batch computes: the PCIe transfer hides behind the kernels.
     size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
-    if (const char *v = std::getenv("RSASA_SUB_ATOMS")) kSubAtoms = (size_t)std::max(100000, std::atoi(v));
+    if (const char *v = tuning_env("RSASA_SUB_ATOMS")) kSubAtoms = (size_t)std::max(100000, std::atoi(v));
     std::vector<size_t> cut{0};        // structure indices where sub-batches begin / end
     if (N >= 2 * kSubAtoms && n_structures > 1) {
         size_t max_sub = 8;
-        if (const char *v = std::getenv("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
+        if (const char *v = tuning_env("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
         const size_t n_sub = std::min<size_t>(max_sub, N / kSubAtoms);
         // The link is the longest leg.  The first sub-batch's upload is not hidden behind anything, and nothing hides
         // the last one's kernels: each gets half a share (RSASA_H2H_TAIL=0: only the first).
-        static const bool half_tail = !(std::getenv("RSASA_H2H_TAIL") && std::atoi(std::getenv("RSASA_H2H_TAIL")) == 0);
+        static const bool half_tail = !(tuning_env("RSASA_H2H_TAIL") && std::atoi(tuning_env("RSASA_H2H_TAIL")) == 0);
         const size_t first = half_tail ? N / (2 * n_sub - 2) : N / (2 * n_sub - 1);
         const size_t share = half_tail ? 2 * first : (N - first) / (n_sub - 1);
         auto boundary = [&](size_t k) { return first + (k - 1) * share; };  // first atom of sub-batch k >= 1
@@ -1585,7 +1608,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     // address space.  Pageable ids, or a sub-batch the per-atom kernels take: the 64-bit ids are uploaded.
     const uint64_t *id_mapped = nullptr;
     bool fold_ids = false;
-    if (piped && id && !std::getenv("RSASA_NO_ID_FOLD")) {
+    if (piped && id && !tuning_env("RSASA_NO_ID_FOLD")) {
         Lattice lat_probe;
         void *dp = nullptr;
         if (n_points >= 1 && n_points <= (1u << 24) && get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
@@ -1601,7 +1624,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
     // Radii on the pipelined path: one-byte codes into the table of the batch's distinct radii (RadiusCodec), coded by
     // the same worker threads.
-    const bool code_radii = piped && !std::getenv("RSASA_NO_RADIUS_CODES");
+    const bool code_radii = piped && !tuning_env("RSASA_NO_RADIUS_CODES");
     // the sub-batches' pinned blocks: radius table | residue offsets | folded ids | radius codes, 16-byte aligned parts
     struct Pack { size_t base = 0, o_res = 0, o_id = 0, o_r8 = 0, bytes = 0; };
     std::vector<Pack> pack(cut.size());
@@ -1636,7 +1659,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     }
     if ((fold_ids || code_radii) && !ctx->fold_pool) {
         unsigned nt = std::thread::hardware_concurrency() / 4;
-        if (const char *v = std::getenv("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
+        if (const char *v = tuning_env("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
         ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)), ctx->node);
         if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
     }
@@ -1831,6 +1854,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             if (stt.bad_input && !err)
                 err = fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius + max radius must be a positive finite number");
             if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
+            else ctx->tuning.deferred_hint = stt.deferred;
         };
         bool used[kSlots] = {};
         if (fold_ids || code_radii) {
@@ -1936,6 +1960,7 @@ int rsasa_context_clone_settings(rsasa_context_t *dst, rsasa_context_t *src)
         simd = src->simd_width; small = src->small_path; overlap = src->overlap_tail; tune = src->tuning;
     }
     std::lock_guard<std::recursive_mutex> lk(dst->mu);
+    tune.deferred_hint = dst->tuning.deferred_hint;  // (a measurement of dst's own batches, not a setting)
     dst->simd_width = simd; dst->small_path = small; dst->overlap_tail = overlap; dst->tuning = tune;
     return RSASA_OK;
 }
@@ -1962,7 +1987,9 @@ static void host_stream_worker(HostStream *hs, int w)
             hs->sub[w]->simd_width = job->simd_width;
             hs->sub[w]->small_path = job->small_path;
             hs->sub[w]->overlap_tail = job->overlap_tail;
+            const uint32_t hint = hs->sub[w]->tuning.deferred_hint;  // (what this context has learnt stays its own)
             hs->sub[w]->tuning = job->tuning;
+            hs->sub[w]->tuning.deferred_hint = hint;
         }
         const int rc = rsasa_calculate_sasa_batch(hs->sub[w], job->x, job->y, job->z, job->radius, job->id, job->structure_offsets,
                                                   job->n_structures, job->probe, job->n_points, job->out_atom,

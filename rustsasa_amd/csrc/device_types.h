@@ -153,6 +153,9 @@ struct OcclusionTuning {
                                   // 6 = 5 for batches of 32 768 atoms or more, 4 below
     uint32_t atoms_per_wave = 0;  // 0 = choose from the batch size
     uint32_t debug_stop = 0;      // RSASA_DEBUG_STOP: skip later kernel stages (WRONG results; timing ablation only)
+    uint32_t deferred_hint = 0xFFFFFFFFu;  // atoms the context's last completed batch left to the general kernel (unknown at
+                                           // first): sizes the launch that works off the next batch's deferred list - a grid-stride
+                                           // loop, so any size is correct; 1 024 workgroups that find an empty list cost 20 us
 };
 
 // Launchers implemented in kernels.hip / occlusion.hip.  Each only enqueues on `stream`.

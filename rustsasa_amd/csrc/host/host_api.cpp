@@ -23,8 +23,11 @@
 #include <stdexcept>
 #include <thread>
 #include <type_traits>
+
+namespace rsasa { const char *tuning_env(const char *name); }  // context.cpp: measurement switches, read only under RSASA_TUNING=1
 #if defined(__SSE2__) && !defined(__HIP_DEVICE_COMPILE__)
 #include <emmintrin.h>  // (the mmCIF short cut finds a row's separators sixteen bytes at a time)
+
 #define RSASA_ROW_SSE2 1
 #endif
 
@@ -1690,7 +1693,7 @@ void run_batch(const OptionValues &o, const std::vector<const Structure *> &pdbs
         s_off.push_back((uint32_t)n_total);
     }
     if (members.empty()) return;
-    const bool trace = std::getenv("RSASA_FILES_TRACE") != nullptr;
+    const bool trace = rsasa::tuning_env("RSASA_FILES_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
     std::vector<float> x(n_total), y(n_total), z(n_total), rad(n_total), atom(n_total, 0.f);
     std::vector<std::uint64_t> id(n_total);
@@ -1808,7 +1811,7 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // -> 10-12 k files/s).  Process-wide, once; RSASA_KEEP_MALLOC_DEFAULTS=1 leaves malloc alone.
     static std::once_flag malloc_once;
     std::call_once(malloc_once, [] {
-        if (std::getenv("RSASA_KEEP_MALLOC_DEFAULTS")) return;
+        if (rsasa::tuning_env("RSASA_KEEP_MALLOC_DEFAULTS")) return;
         mallopt(M_TRIM_THRESHOLD, 1 << 30);
         mallopt(M_TOP_PAD, 256 << 20);
         mallopt(M_MMAP_THRESHOLD, 32 << 20);
@@ -1822,7 +1825,7 @@ std::vector<Result<typename Level::Output>> process_files(const std::vector<std:
     // (chunks of 512 files and two GPU workers: 16.4 k files/s on the 4 363-file set against 13.3 k with 256 and one
     // shared context - fewer per-chunk joins of the parse pool, and one chunk's upload beside the other's kernels)
     if (files_per_batch == 0) files_per_batch = 512;
-    const bool fast_reader = std::getenv("RSASA_NO_FAST_READER") == nullptr;
+    const bool fast_reader = rsasa::tuning_env("RSASA_NO_FAST_READER") == nullptr;
     // one worker per given context; with a single context a second, private one on the same device joins it
     // for the duration of the call (calls on one context are serialised)
     std::vector<rsasa_context_t *> contexts = o.contexts;

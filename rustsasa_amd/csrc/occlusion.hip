@@ -40,6 +40,8 @@
 // test uses the reference's exact f32 expressions.
 #include "device_utils.h"
 
+#include <atomic>
+
 namespace rsasa {
 namespace {
 
@@ -77,13 +79,30 @@ void launch_fast2(bool half1, uint32_t n_blocks, hipStream_t stream, const OccAr
     else hipLaunchKernelGGL((k_occlusion_fast<HAS_ID, HAS_REM, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
 }
 
+// Compute units of the current device (persistent launches are sized by what the GPU holds at once: 256 on MI355X; a
+// partitioned or different device gets its own count; results never depend on it).  The per-XCD pieces of such a launch
+// (occlusion_mx.inc) assume eight XCDs dealt round-robin: on another layout the pieces only lose their L2 locality.
+uint32_t device_cus()
+{
+    static std::atomic<uint32_t> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256u;
+    uint32_t n = cached[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        int cu = 0;
+        n = (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0) ? (uint32_t)cu : 256u;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 // NW waves per workgroup, each with up to atoms_per_wave atoms
 template <int NT, bool MULTI, int NW>
 void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
 {
     // persistent waves (occlusion_mx.inc): as many workgroups as the GPU holds at once - 28 waves per CU at 72
     // registers, 24 at 80 (NW >= 8) - or fewer when the batch has fewer blocks of atoms_per_wave atoms than that
-    const uint32_t resident = 256u * (NW == 4 ? 7u : NW == 8 ? 3u : 2u);
+    const uint32_t resident = device_cus() * (NW == 4 ? 7u : NW == 8 ? 3u : 2u);
     const uint32_t n_blocks = mx_persistent(MULTI) ? min(cdiv(n_atoms, NW * a3.atoms_per_wave), resident) : cdiv(n_atoms, NW * a3.atoms_per_wave);
     if (mx_persistent(MULTI)) (void)hipMemsetAsync(a3.claim, 0, 8u * kClaimStride * 4u, stream);  // (a failure shows as the launch's)
     if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
@@ -102,16 +121,20 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
 #endif
 constexpr uint32_t kMxLdsBudget = 157u * 1024u;  // what workgroups of k_occlusion_mx can share of a CU's 160 KB (see launch_occlusion)
 
-// static LDS of the many-point instantiations per wave (the same for every NW: the lists are per wave)
+// static LDS of the many-point instantiations per wave (the same for every NW: the lists are per wave).  Contexts on
+// several host threads may launch at once: the cached value is an atomic (every thread that finds it empty stores the
+// same number).
 uint32_t mx_multi_lds_per_wave()
 {
-    static uint32_t bytes = 0;
+    static std::atomic<uint32_t> cached{0};
+    uint32_t bytes = cached.load(std::memory_order_relaxed);
     if (!bytes) {
         hipFuncAttributes at{};
         if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(&k_occlusion_mx<8, true, true, true, 4>)) == hipSuccess && at.sharedSizeBytes)
             bytes = (uint32_t)at.sharedSizeBytes / 4u;
         else
             bytes = 3584u;
+        cached.store(bytes, std::memory_order_relaxed);
     }
     return bytes;
 }
@@ -221,7 +244,10 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
         a3.work_list = b.deferred_list;
         a3.work_count = &b.status->deferred;
         a3.atoms_per_wave = 1;
-        const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), 1024u);  // (grid-stride over the list: usually empty)
+        // grid-stride over the list, which is usually empty: as many workgroups as the last batch's list would have kept
+        // busy twice over (16 at least; all 1 024 while nothing is known)
+        const uint32_t want = tune.deferred_hint == 0xFFFFFFFFu ? 1024u : min(1024u, max(16u, cdiv(tune.deferred_hint, 2u)));
+        const uint32_t n_blocks = min(cdiv(b.n_atoms, 4), want);
         if (b.id) hipLaunchKernelGGL((k_occlusion_v3<2, true, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
         else hipLaunchKernelGGL((k_occlusion_v3<2, false, false>), dim3(n_blocks), dim3(256), 0, stream, a3);
         return;

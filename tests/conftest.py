@@ -4,6 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the library reads its measurement switches (RSASA_OCCLUSION_KERNEL, RSASA_SUB_ATOMS, ...: kernel variants and paths the
+# tests force) only when the process says RSASA_TUNING=1 - once, at its first use
+os.environ.setdefault("RSASA_TUNING", "1")
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)

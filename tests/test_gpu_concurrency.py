@@ -230,3 +230,26 @@ def test_stream_of_host_batches_runs_with_the_callers_lane_count():
             ctx.host_batch_wait()
             want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, w, threads=0)
             assert np.array_equal(atom, want), w
+
+
+def test_measurement_switches_are_read_only_under_rsasa_tuning():
+    """The library's RSASA_* switches (kernel choice, sub-batch sizes, traces) are measurement aids: a production
+    process that happens to have one in its environment computes as if it had not.  Two child processes run the same
+    host batch with RSASA_SUB_ATOMS=100000 and RSASA_H2H_TRACE=1 set: only the one that also says RSASA_TUNING=1 cuts
+    the batch into sub-batches and traces them."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np; import bench_workloads as bw; import rustsasa_amd\n"
+            "b = bw.synthetic_proteome(100, seed=3)\n"
+            "with rustsasa_amd.Context(0) as c:\n"
+            "    a, _ = c.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, 1.4, 100)\n"
+            "print('TOTAL %%.3f' %% float(a.sum(dtype=np.float64)))\n") % ROOT
+    totals = {}
+    for tuning in ("0", "1"):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("RSASA_")}
+        env.update(RSASA_SUB_ATOMS="100000", RSASA_H2H_TRACE="1", RSASA_TUNING=tuning)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        totals[tuning] = [ln for ln in p.stdout.splitlines() if ln.startswith("TOTAL")][0]
+        assert ("h2h ctx" in p.stderr) == (tuning == "1"), p.stderr[-500:]
+    assert totals["0"] == totals["1"]

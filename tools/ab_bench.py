@@ -10,6 +10,7 @@ child processes whose loader points at the variant, and prints the occlusion-ker
 import glob
 import json
 import os
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import subprocess
 import sys
 

@@ -3,6 +3,7 @@
 # (results are wrong in those runs; only the kernel time and instruction counts are read).
 # The switch exists only in the ablation library: build it first with
 #   make -C rustsasa_amd/csrc ablate            (-> rustsasa_amd/lib/variants/ablate/)
+export RSASA_TUNING=1  # (the library reads its RSASA_* measurement switches only then)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 LIB=$PWD/rustsasa_amd/lib/variants/ablate/librustsasa_amd.so
 RUN="import sys; sys.path.insert(0, '.'); import rustsasa_amd._capi as c; c.LIB_PATH = '$LIB'; import bench; bench.main()"

@@ -11,6 +11,7 @@ number; bench.py's `value` is the HBM-resident hot path only.
 import argparse
 import json
 import os
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import subprocess
 import sys
 import tempfile

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Host-to-host rate (pinned SoA in, residue values out) of the proteome batch for several sub-batch counts."""
 import os, sys, time
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

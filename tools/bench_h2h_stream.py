@@ -3,6 +3,7 @@
 same GPU, call rsasa_calculate_sasa_batch back to back on the proteome batch - call k + 1's uploads cross the link
 while call k's last sub-batches compute and download.  Prints ms per batch for T = 1, 2, 3."""
 import os, sys, time, threading
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

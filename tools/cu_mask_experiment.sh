@@ -2,6 +2,7 @@
 # usage (GPU box): tools/cu_mask_experiment.sh   -> gpurun_out/cu_mask.txt
 # RSASA_GRID_CUS=N sets N compute units aside for the grid builds (a CU-masked stream) and masks the launch streams to
 # the others: does hiding the grid build behind the occlusion kernel pay for the CUs that kernel loses?  
+export RSASA_TUNING=1  # (the library reads its RSASA_* measurement switches only then)
 out=gpurun_out/cu_mask.txt
 : > $out
 args="--steps 40 --warmup 5 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0"

@@ -2,6 +2,7 @@
 """Host-side timeline of a stream of host batches (RSASA_H2H_TRACE=1): six proteome batches through
 rsasa_host_batch_enqueue / _wait, the phases of every call on one clock (stderr)."""
 import os, sys, time
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 os.environ["RSASA_H2H_TRACE"] = "1"
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

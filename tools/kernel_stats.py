@@ -6,6 +6,7 @@ neighbour-count output (results stay correct).  Prints the means; used together 
 tools/isa_blocks.py to attribute instruction counts to stages.
 """
 import os
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import sys
 
 import numpy as np

@@ -11,6 +11,7 @@ about a seventh of these per atom and SIMD).  A stamp costs the wave about as mu
 build's kernel time is printed beside the plain one."""
 import ctypes as C
 import os
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

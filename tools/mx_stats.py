@@ -3,6 +3,7 @@
    make -C rustsasa_amd/csrc OUT=../lib/variants/statN/librustsasa_amd.so EXTRA=-DMX_STAT=N ...  (N = 1: survivors of
 phase A, 2: near candidates, 3: candidate tiles); each reports its quantity through the neighbour-count output."""
 import os
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import subprocess
 import sys
 

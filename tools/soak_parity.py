@@ -3,6 +3,7 @@
 sparse, dense clusters, coincident atoms), radii, ids (some duplicated) and point counts, every atom compared
 with the oracle.  usage: tools/soak_parity.py [seconds] [seed]"""
 import os, sys, time
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -8,6 +8,7 @@ Thread 0 of every workgroup stamps s_memrealtime (10 ns ticks) behind the barrie
 workgroups of one launch are printed per phase, as a share and as microseconds per workgroup."""
 import ctypes as C
 import os
+os.environ.setdefault("RSASA_TUNING", "1")  # (the library reads its RSASA_* measurement switches only then)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
