@@ -52,35 +52,56 @@ out = {
     "salu_insts_per_launch": val("SQ_INSTS_SALU"),
     "kernel_source_sha16": bench_py.kernel_source_hash(),
 }
-PRICE = 1.3  # real shader cycles a SIMD spends per vector instruction at this kernel's occupancy: MODELLED, from
-             # tools/microbench_clock.hip (dependent v_fma streams on 8 waves per SIMD: 1.30) and from the kernel itself
-             # (20 / 40 extra v_mov per atom: +1.15 / +1.3 cycles per atom and SIMD each; 20 s_mov: +1.4): DESIGN 6a
+# Prices, validated in round 5 (tools/microbench_clock.hip with HW_ID-observed residency, profiles/round5_microbench_clock.txt):
+# a wave64 vector instruction occupies its SIMD-32 for 2 cycles (datasheet: 64 FLOP / clk / SIMD; measured 2.2 over the
+# whole span of 7-8 resident waves, 5.2 for one wave alone - latency); a scalar instruction takes one of the CU's scalar
+# issue slots, one per cycle and CU (measured: 4.2 cycles per instruction and SIMD with all four SIMDs issuing), so does a
+# vector compare that writes an SGPR pair (4.1); round 4's "1.3 cycles per instruction of any kind" divided by an
+# assumed residency and implied 1.54 x the datasheet's vector rate.
+VECTOR_CYCLES = 2.0
 
 
 def alu_busy(v, cyc):
-    """Vector + matrix pipe occupancy of one dispatch.  Two variants of the same model: the matrix instructions at the
-    cycles SQ_VALU_MFMA_BUSY_CYCLES counts, the other vector instructions at PRICE cycles each, over the kernel's
-    cycles on the 1024 SIMDs - with and without the cycles in which both kinds were in flight at once
-    (SQ_VALU_MFMA_COEXEC_CYCLES).  Neither is a counter; the instruction counts and the busy cycles are."""
+    """How busy the units of a CU were over one dispatch, from counters and the validated prices above (a MODEL where a
+    price is involved: `modelled`): vector ALU = (vector - matrix instructions) x 2 cycles per SIMD; matrix pipe =
+    SQ_VALU_MFMA_BUSY_CYCLES per SIMD (a counter), and the two minus the cycles both were in flight
+    (SQ_VALU_MFMA_COEXEC_CYCLES); scalar unit = (scalar + branch + scalar-memory instructions) x 1 cycle per CU; LDS pipe =
+    SQ_LDS_IDX_ACTIVE per CU (a counter); wave slots = SQ_WAVE_CYCLES x 4 over the cycles of the seven slots per SIMD."""
     mfma, busy, coexec = v("SQ_INSTS_MFMA"), v("SQ_VALU_MFMA_BUSY_CYCLES"), v("SQ_VALU_MFMA_COEXEC_CYCLES")
     valu = v("SQ_INSTS_VALU")
-    other = {k: v(k) for k in ("SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD")}
-    all_insts = valu + sum(other.values())
-    return {
+
+    def opt(name):
+        try:
+            return v(name)
+        except Exception:  # noqa: BLE001  (a pass that was not collected)
+            return None
+    salu, branch, smem, lds_i = opt("SQ_INSTS_SALU"), opt("SQ_INSTS_BRANCH"), opt("SQ_INSTS_SMEM"), opt("SQ_INSTS_LDS")
+    lds_active, wave_cyc, vmem = opt("SQ_LDS_IDX_ACTIVE"), opt("SQ_WAVE_CYCLES"), opt("SQ_INSTS_VMEM_RD")
+    out = {
         "modelled": True,
-        "price_cycles_per_vector_inst": PRICE,
-        "price_source": "tools/microbench_clock.hip (real shader cycles, 8 waves per SIMD) and the in-kernel pad experiment (DESIGN 6a)",
+        "vector_cycles_per_inst": VECTOR_CYCLES,
+        "price_source": "datasheet rate (64 FLOP / clk / SIMD); tools/microbench_clock.hip with observed residency measures 2.2 "
+                        "(profiles/round5_microbench_clock.txt); scalar unit: one instruction per cycle and CU (4.2 cycles per "
+                        "instruction and SIMD measured with four SIMDs issuing)",
         "mfma_insts_per_launch": mfma, "mfma_busy_cycles_per_launch": busy, "mfma_valu_coexec_cycles_per_launch": coexec,
         "kernel_cycles": round(cyc),
-        "frac_sum": round(((valu - mfma) * PRICE + busy) / 1024 / cyc, 3),
-        "frac_minus_coexec": round(((valu - mfma) * PRICE + busy - coexec) / 1024 / cyc, 3),
-        "insts_all_classes_per_launch": all_insts,
-        "issue_frac": round((all_insts * PRICE + busy) / 1024 / cyc, 3),
-        "definition": "frac_sum = ((vector - matrix instructions) x price + SQ_VALU_MFMA_BUSY_CYCLES) / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8); "
-                      "frac_minus_coexec subtracts SQ_VALU_MFMA_COEXEC_CYCLES; issue_frac prices EVERY instruction (vector, scalar, "
-                      "branch, LDS, vector memory) at the same cycles - the pad experiment finds a scalar instruction no cheaper "
-                      "than a vector one - plus the matrix pipe's busy cycles",
+        "vector_busy": round((valu - mfma) * VECTOR_CYCLES / 1024 / cyc, 3),
+        "matrix_busy": round(busy / 1024 / cyc, 3),
+        "frac_sum": round(((valu - mfma) * VECTOR_CYCLES + busy) / 1024 / cyc, 3),
+        "frac_minus_coexec": round(((valu - mfma) * VECTOR_CYCLES + busy - coexec) / 1024 / cyc, 3),
+        "definition": "per SIMD: vector_busy = (vector - matrix instructions) x 2 cycles, matrix_busy = SQ_VALU_MFMA_BUSY_CYCLES, "
+                      "frac_sum their sum, frac_minus_coexec without SQ_VALU_MFMA_COEXEC_CYCLES; per CU: scalar_busy = (scalar + "
+                      "branch + scalar-memory instructions) x 1 cycle, lds_busy = SQ_LDS_IDX_ACTIVE; all over GRBM_GUI_ACTIVE / 8 of "
+                      "the profiled launch; wave_slots_used = SQ_WAVE_CYCLES x 4 / (cycles x 1024 SIMDs x 7 waves)",
     }
+    if salu is not None and branch is not None:
+        out["scalar_busy"] = round((salu + branch + (smem or 0)) / 256 / cyc, 3)
+        out["insts_all_classes_per_launch"] = valu + salu + branch + (lds_i or 0) + (vmem or 0)
+    if lds_active is not None:
+        out["lds_busy"] = round(lds_active / 256 / cyc, 3)
+    if wave_cyc is not None:
+        out["wave_slots_used"] = round(wave_cyc * 4 / (cyc * 1024 * 7), 3)
+    return out
 
 
 try:
