@@ -10,12 +10,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "round3_final"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "round5_final"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
                                         "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json", "pmc_uniform1m.txt",
-                                        "files_mode_1500.json", "files_mode_cif.json", "bench_shard_of_8.json", "two_in_flight.txt", "bench_run2.json")}
+                                        "files_mode_1500.json", "files_mode_cif.json", "bench_shard_of_8.json", "two_in_flight.txt", "bench_run2.json",
+                                        "microbench_clock.txt", "h2h_stream.txt")}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 10:
@@ -61,7 +62,7 @@ out = {
 VECTOR_CYCLES = 2.0
 
 
-def alu_busy(v, cyc):
+def alu_busy(v, cyc, slots=7):
     """How busy the units of a CU were over one dispatch, from counters and the validated prices above (a MODEL where a
     price is involved: `modelled`): vector ALU = (vector - matrix instructions) x 2 cycles per SIMD; matrix pipe =
     SQ_VALU_MFMA_BUSY_CYCLES per SIMD (a counter), and the two minus the cycles both were in flight
@@ -92,7 +93,7 @@ def alu_busy(v, cyc):
         "definition": "per SIMD: vector_busy = (vector - matrix instructions) x 2 cycles, matrix_busy = SQ_VALU_MFMA_BUSY_CYCLES, "
                       "frac_sum their sum, frac_minus_coexec without SQ_VALU_MFMA_COEXEC_CYCLES; per CU: scalar_busy = (scalar + "
                       "branch + scalar-memory instructions) x 1 cycle, lds_busy = SQ_LDS_IDX_ACTIVE; all over GRBM_GUI_ACTIVE / 8 of "
-                      "the profiled launch; wave_slots_used = SQ_WAVE_CYCLES x 4 / (cycles x 1024 SIMDs x 7 waves)",
+                      "the profiled launch; wave_slots_used = SQ_WAVE_CYCLES x 4 / (cycles x 1024 SIMDs x wave_slots_per_simd)",
     }
     if salu is not None and branch is not None:
         out["scalar_busy"] = round((salu + branch + (smem or 0)) / 256 / cyc, 3)
@@ -100,7 +101,8 @@ def alu_busy(v, cyc):
     if lds_active is not None:
         out["lds_busy"] = round(lds_active / 256 / cyc, 3)
     if wave_cyc is not None:
-        out["wave_slots_used"] = round(wave_cyc * 4 / (cyc * 1024 * 7), 3)
+        out["wave_slots_used"] = round(wave_cyc * 4 / (cyc * 1024 * slots), 3)
+        out["wave_slots_per_simd"] = slots
     return out
 
 
@@ -123,7 +125,7 @@ if os.path.exists(pu):
             "salu_insts_per_launch": vu("SQ_INSTS_SALU"), "lds_insts_per_launch": vu("SQ_INSTS_LDS"),
             "kernel_source_sha16": bench_py.kernel_source_hash()}
     try:
-        outu["alu_busy"] = alu_busy(vu, vu("GRBM_GUI_ACTIVE") / 8.0)
+        outu["alu_busy"] = alu_busy(vu, vu("GRBM_GUI_ACTIVE") / 8.0, slots=6)  # (80 registers, LDS: six waves per SIMD)
     except Exception as e:
         print("no alu_busy for the many-point dispatch:", e)
     json.dump(outu, open(os.path.join(dst, "pmc_uniform1m.json"), "w"), indent=2)
