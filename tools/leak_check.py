@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Memory growth check on the GPU box: repeats the host-batch, device-batch (two in flight) and per-structure entry
-points and prints the process RSS and the free device memory before and after.  usage: tools/leak_check.py [rounds]"""
+"""Memory growth check on the GPU box: repeats the host-batch, device-batch (two in flight), host-batch-stream
+(rsasa_host_batch_enqueue / _wait, three queued) and per-structure entry points, creates and destroys contexts that have
+run a stream (their two worker contexts and threads go with them), and prints the process RSS and the free device memory before and after.  usage: tools/leak_check.py [rounds]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,6 +39,13 @@ with rustsasa_amd.Context(0) as ctx:
             ctx.wait_all()
             for _ in range(20):
                 ctx.calculate_sasa_soa(one.x, one.y, one.z, one.radius, one.ids)
+            for k in range(3):
+                ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, residue_offsets=b.residue_offsets, want_atoms=k == 1)
+            ctx.host_batch_wait_all()
+            if i % 10 == 0:
+                with rustsasa_amd.Context(0) as c2:   # a context that has run a stream: created and destroyed
+                    c2.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, want_atoms=True)
+                    c2.host_batch_wait()
 
     cycle(10)  # buffers reach their sizes
     torch.cuda.synchronize()

@@ -57,15 +57,27 @@ with rustsasa_amd.Context(0) as ctx:
         probe = float(rng.choice([1.4, 1.4, 1.4, 0.0, 0.7, 2.5]))
         if len(xyz) < 3000 and rng.random() < 0.1:
             probe = 33.0  # (a probe the matrix-core kernel does not take; the oracle needs minutes for it on large inputs)
+        if rng.random() < 0.06 and len(xyz) > 10:  # NaN coordinates (either sign) and radii: the reference's arithmetic, bit for bit
+            k = rng.integers(len(xyz), size=int(rng.integers(1, 6)))
+            xyz[k, rng.integers(3, size=len(k))] = np.array([0x7FC00000, 0xFFC00000], np.uint32).view(np.float32)[rng.integers(2, size=len(k))]
+            if rng.random() < 0.5:
+                r[rng.integers(len(r))] = np.nan
         x, y, z = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
         # random residues: consecutive runs of atoms that never cross a structure boundary
         cuts = set(so.tolist())
         if len(xyz):
             cuts.update(rng.integers(0, len(xyz), size=max(1, len(xyz) // 9)).tolist())
         ro = np.array(sorted(cuts), np.uint32)
-        mode = rng.integers(3)
+        mode = rng.integers(4)
         if mode == 0:    # host arrays in, host arrays out
             got, got_res = ctx.calculate_sasa_batch(x, y, z, r, use_ids, so, probe, n_points, residue_offsets=ro)
+            got_k = None
+        elif mode == 3:  # the same as a stream of host batches (two queued: this one twice)
+            got, got_res = ctx.host_batch_enqueue(x, y, z, r, use_ids, so, probe, n_points, residue_offsets=ro)
+            got2, _ = ctx.host_batch_enqueue(x, y, z, r, use_ids, so, probe, n_points, residue_offsets=ro)
+            ctx.host_batch_wait(); ctx.host_batch_wait()
+            if not np.array_equal(got, got2, equal_nan=True):
+                print(f"STREAM MISMATCH between the two queued copies, iteration {it}"); sys.exit(1)
             got_k = None
         else:            # device-resident, with the per-atom candidate counts
             dev = torch.device("cuda:0")
@@ -93,10 +105,10 @@ with rustsasa_amd.Context(0) as ctx:
                                                           probe, n_points, 8, return_details=True)
                     if not np.array_equal(got_k[s0:s1], wk):
                         print(f"K MISMATCH iteration {it}"); sys.exit(1)
-        if not np.array_equal(got_res, want_res):
+        if not np.array_equal(got_res, want_res, equal_nan=True):
             print(f"RESIDUE MISMATCH iteration {it}: {int((got_res != want_res).sum())} of {len(want_res)}"); sys.exit(1)
-        if not np.array_equal(got, want):
-            bad = np.flatnonzero(got != want)
+        if not np.array_equal(got, want, equal_nan=True):
+            bad = np.flatnonzero(~((got == want) | (np.isnan(got) & np.isnan(want))))
             np.savez("soak_failure.npz", xyz=xyz, r=r, so=so, ids=ids, n_points=n_points, probe=probe)
             print(f"MISMATCH iteration {it}: {len(bad)} of {len(got)} atoms differ (first {bad[:5]}), saved soak_failure.npz")
             sys.exit(1)
