@@ -48,6 +48,24 @@ int main(void)
     if (rsasa_context_set_simd_width(ctx, 8) != RSASA_OK) return 25;
     if (rsasa_context_bind_thread(ctx, &node) != RSASA_OK || node < -1) return 26;
     if (rsasa_batch_wait_all(ctx) != RSASA_OK || rsasa_batch_wait(ctx) != RSASA_OK) return 27;
+    /* ABI 3: a second context with the first one's settings; a stream of host batches: two queued, waited for in order,
+     * a wait with nothing queued returns at once */
+    {
+        rsasa_context_t *other = NULL;
+        int w2 = 0;
+        if (rsasa_context_create(0, &other) != RSASA_OK) return 28;
+        if (rsasa_context_set_simd_width(ctx, 16) != RSASA_OK || rsasa_context_clone_settings(other, ctx) != RSASA_OK ||
+            rsasa_context_get_simd_width(other, &w2) != RSASA_OK || w2 != 16) return 29;
+        if (rsasa_context_set_simd_width(ctx, 8) != RSASA_OK || rsasa_context_destroy(other) != RSASA_OK) return 30;
+        float x[3] = {0.f, 4.f, 40.f}, y[3] = {0.f, 0.f, 0.f}, z[3] = {0.f, 0.f, 0.f}, rad[3] = {2.f, 2.f, 2.f};
+        uint32_t so[2] = {0u, 3u};
+        float a1[3] = {-1.f, -1.f, -1.f}, a2[3] = {-1.f, -1.f, -1.f};
+        if (rsasa_host_batch_wait(ctx) != RSASA_OK) return 31;
+        if (rsasa_host_batch_enqueue(ctx, x, y, z, rad, NULL, so, 1, 1.4f, 5000, a1, NULL, 0, NULL) != RSASA_OK) return 32;
+        if (rsasa_host_batch_enqueue(ctx, x, y, z, rad, NULL, so, 1, 1.4f, 5000, a2, NULL, 0, NULL) != RSASA_OK) return 33;
+        if (rsasa_host_batch_wait(ctx) != RSASA_OK || a1[0] != out[0] || a1[2] != out[2]) return 34;
+        if (rsasa_host_batch_wait_all(ctx) != RSASA_OK || a2[1] != out[1]) return 35;
+    }
     /* empty input is valid and touches nothing */
     if (rsasa_calculate_sasa_internal(ctx, NULL, 0, 1.4f, 100, 1, NULL) != RSASA_OK) return 20;
     /* invalid arguments are reported, not crashed on */
