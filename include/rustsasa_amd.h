@@ -165,7 +165,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
  * context's last error); with nothing enqueued it returns RSASA_OK at once.
  * Every buffer of a batch - inputs and outputs - belongs to the library from
  * the enqueue until the wait that returns the batch.  Pinned (page-locked)
- * host memory makes all copies asynchronous, as for the synchronous call. */
+ * host memory makes all copies asynchronous, as for the synchronous call.
+ * The two worker contexts create their streams on hardware queues of their
+ * own (the runtime otherwise multiplexes a process's streams onto four
+ * queues, and two streams that share one run in order: nothing overlaps). */
 int rsasa_host_batch_enqueue(rsasa_context_t *ctx, const float *x, const float *y,
                              const float *z, const float *radius, const uint64_t *id,
                              const uint32_t *structure_offsets, size_t n_structures,

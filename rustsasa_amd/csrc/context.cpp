@@ -318,8 +318,33 @@ private:
 // rsasa_host_batch_enqueue / _wait: a stream of host batches on one context handle.  Two worker threads, each with a
 // private context on the caller's GPU, run rsasa_calculate_sasa_batch on the queued batches in order; the link turn
 // (LinkTurn, below) lets the second call's uploads follow the first one's.  Results are handed back oldest first.
+// The order in which the calls of one stream take their turns on the link is the order of the batches: the caller waits
+// for the OLDEST batch, and a younger one that slipped ahead on the link delays exactly that one (two workers woken
+// together: the second batch uploaded first, the first one's results came after both, and the caller - who enqueues the
+// next batch when the oldest returns - kept one batch in flight where it meant two).
+struct LinkGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t next = 1;  // the ticket whose turn it is
+    void wait_for(uint64_t ticket)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return next >= ticket; });
+    }
+    void advance(uint64_t ticket)  // `ticket` has queued its uploads (or will not queue any): idempotent
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (next > ticket) return;
+            next = ticket + 1;
+        }
+        cv.notify_all();
+    }
+};
+
 struct HostStream {
     struct Job {
+        uint64_t ticket = 0;
         const float *x, *y, *z, *radius;
         const uint64_t *id;
         const uint32_t *structure_offsets;
@@ -338,13 +363,20 @@ struct HostStream {
         std::string error;
         bool taken = false, done = false;
     };
-    static constexpr int kWorkers = 2;
+    static constexpr int kMaxWorkers = 4;
+    int n_workers = 2;
+    // The workers' contexts create their streams on hardware queues of their own (new_stream).  The next call's uploads
+    // hide a call's fill and drain, so each call is cut into two sub-batches only (measured, ms per proteome batch:
+    // 2 sub-batches 4.30, 3 5.15, 8 5.29; on the pooled queues 6.40 / 6.53 / 5.34).
+    size_t sub_batches = 0;
     static constexpr size_t kMaxQueued = 8;  // enqueued and not yet waited for (a further enqueue waits for the oldest to complete)
-    rsasa_context *sub[kWorkers] = {nullptr, nullptr};
-    std::thread th[kWorkers];
+    rsasa_context *sub[kMaxWorkers] = {};
+    std::thread th[kMaxWorkers];
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::deque<std::shared_ptr<Job>> jobs;  // oldest first; entries leave in rsasa_host_batch_wait
+    uint64_t next_ticket = 1;
+    LinkGate gate;
     bool quit = false;
 };
 
@@ -410,7 +442,7 @@ struct rsasa_context {
     DeviceBuffer in_pack[kSlots];                 // that block of the sub-batch in slot k, on the device
     char *h_pack = nullptr;                       // pinned: the blocks of a whole host batch
     size_t h_pack_cap = 0;
-    FoldPool *fold_pool = nullptr;                // created by the first large (pipelined) host call
+    FoldPool *fold_pool = nullptr;                // the device's shared coding pool (first large host call; never owned)
     RadiusCodec radius_codec;
     hipStream_t copy_stream = nullptr;            // H2D of the next sub-batch while the current one computes
     hipStream_t d2h_stream = nullptr;             // D2H of the previous sub-batch's results meanwhile
@@ -441,6 +473,11 @@ struct rsasa_context {
     int head = 0, n_pending = 0;
     OcclusionTuning tuning;
     hipEvent_t ev_link = nullptr;  // recorded behind the last upload of a pipelined host call (LinkTurn)
+    hipEvent_t tr_ev[8][4] = {};   // RSASA_H2H_TRACE: a sub-batch's uploads and kernels, start and end
+    LinkGate *link_gate = nullptr; // a worker context of a stream of host batches: the calls take the link in ticket order
+    uint64_t link_ticket = 0;
+    int own_queues = 0;            // 1: the copy streams, 2: every stream on a hardware queue of its own (new_stream)
+    size_t stream_sub_batches = 0; // a worker context of a stream of host batches: most sub-batches of a call (0: the default)
     struct HostStream *host_stream = nullptr;  // rsasa_host_batch_enqueue / _wait: two workers with a context each
 };
 
@@ -520,6 +557,7 @@ struct LinkHold {
         if (c->device < 0 || c->device >= 64) return hipSuccess;
         lt = &g_link[c->device];
         ctx = c;
+        if (c->link_gate) c->link_gate->wait_for(c->link_ticket);
         hipEvent_t prev = nullptr;
         {
             std::unique_lock<std::mutex> lk(lt->mu);
@@ -539,14 +577,15 @@ struct LinkHold {
         if (ok) { lt->last = ctx->ev_link; lt->owner = ctx; }
         lt->busy = false;
         held = false;
-        lt->cv.notify_one();
+        lt->cv.notify_all();
+        if (ctx->link_gate) ctx->link_gate->advance(ctx->link_ticket);
     }
     ~LinkHold()
     {
         if (!held) return;  // (an error return: nothing to order behind)
         std::lock_guard<std::mutex> lk(lt->mu);
         lt->busy = false;
-        lt->cv.notify_one();
+        lt->cv.notify_all();
     }
 };
 
@@ -692,16 +731,35 @@ int get_lattice(rsasa_context *ctx, size_t n_points, Lattice *out)
 // process's streams onto a few hardware queues in creation order: a context that only serves
 // per-structure calls should hold ONE stream, or the launch streams of several contexts (one per host
 // thread) all land on the same queue and their kernels run one after the other.
+//
+// own_queues (the worker contexts of a stream of host batches): a stream created with a CU mask gets a hardware queue
+// of its own instead of one from the shared pool, and a mask of every CU restricts nothing.  Streams that share a
+// queue run their packets in order - the barrier that makes one worker's kernels wait for its upload would hold the
+// other worker's kernels behind it, and the stream of batches would not overlap (measured: 6.6 ms per proteome batch
+// on pooled queues that collide, 4.4 on queues of their own).
+hipError_t new_stream(rsasa_context *ctx, hipStream_t *out, int level)
+{
+    if (ctx->own_queues >= level) {
+        int n_cu = 0;
+        uint32_t mask[16] = {};
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n_cu > 0 && n_cu <= 512) {
+            for (int c = 0; c < n_cu; c++) mask[c / 32] |= 1u << (c % 32);
+            return hipExtStreamCreateWithCUMask(out, (uint32_t)(n_cu + 31) / 32, mask);
+        }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 int ensure_side_stream(rsasa_context *ctx)
 {
-    if (!ctx->side_stream) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    if (!ctx->side_stream) RS_HIP(ctx, new_stream(ctx, &ctx->side_stream, 2));
     return RSASA_OK;
 }
 
 int ensure_copy_streams(rsasa_context *ctx)
 {
-    if (!ctx->copy_stream) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    if (!ctx->d2h_stream) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream) RS_HIP(ctx, new_stream(ctx, &ctx->copy_stream, 1));
+    if (!ctx->d2h_stream) RS_HIP(ctx, new_stream(ctx, &ctx->d2h_stream, 1));
     return RSASA_OK;
 }
 
@@ -989,7 +1047,14 @@ int rsasa_device_count(int *out_count)
     return RSASA_OK;
 }
 
+static int context_create(int device, int own_queues, rsasa_context_t **out_ctx);
+
 int rsasa_context_create(int device, rsasa_context_t **out_ctx)
+{
+    return context_create(device, 0, out_ctx);
+}
+
+static int context_create(int device, int own_queues, rsasa_context_t **out_ctx)
 {
     if (!out_ctx) return RSASA_ERR_INVALID_ARGUMENT;
     *out_ctx = nullptr;
@@ -1002,6 +1067,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
     rsasa_context *ctx = new (std::nothrow) rsasa_context();
     if (!ctx) return RSASA_ERR_OUT_OF_MEMORY;
     ctx->device = device;
+    ctx->own_queues = own_queues;
     ctx->node = device_node_cpus(device);
     DeviceGuard guard(device);
     hipError_t e = guard.err;
@@ -1030,7 +1096,7 @@ int rsasa_context_create(int device, rsasa_context_t **out_ctx)
         for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid[w], hipEventDisableTiming);
         for (int w = 0; w < 2 && e == hipSuccess; w++) e = hipEventCreateWithFlags(&ctx->ev_grid_in[w], hipEventDisableTiming);
     } else if (e == hipSuccess) {
-        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        e = new_stream(ctx, &ctx->stream, 2);
         // Experiment (RSASA_GRID_PRIO=1): the grid builds on a stream of the highest priority, so that their workgroups -
         // shaped to fit the slot an occlusion workgroup leaves - are dispatched ahead of the other batch's
         if (e == hipSuccess && tuning_env("RSASA_GRID_PRIO")) {
@@ -1101,7 +1167,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     for (DeviceBuffer &b : ctx->in_pack) release(b);
     for (auto &m : ctx->more)
         for (DeviceBuffer *b : {&m.x, &m.y, &m.z, &m.r, &m.id, &m.res, &m.atom_sasa, &m.out_res}) release(*b);
-    delete ctx->fold_pool;
+    // (the coding pool is the device's, shared by its contexts: it stays)
     if (ctx->h_pack) (void)hipHostFree(ctx->h_pack);
     for (auto &kv : ctx->lattices)
         if (kv.second.d) (void)hipFree(kv.second.d);
@@ -1145,6 +1211,9 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
         if (g_link[ctx->device].owner == ctx) { g_link[ctx->device].last = nullptr; g_link[ctx->device].owner = nullptr; }
     }
     if (ctx->ev_link) (void)hipEventDestroy(ctx->ev_link);
+    for (auto &row : ctx->tr_ev)
+        for (hipEvent_t e : row)
+            if (e) (void)hipEventDestroy(e);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1264,7 +1333,7 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
         if ((rc = wait_oldest(ctx))) return rc;
     const int w = ctx->n_pending ? ctx->pending[ctx->head].ws ^ 1 : 0;
     if (w == 1 && !hip_stream && !ctx->stream2)
-        RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        RS_HIP(ctx, new_stream(ctx, &ctx->stream2, 2));
     Pending &pd = ctx->pending[ctx->head ^ (ctx->n_pending ? 1 : 0)];
     pd = Pending{};
     pd.batch = *batch;
@@ -1520,9 +1589,27 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     RS_DEVICE(ctx);
     static const bool h2h_trace = tuning_env("RSASA_H2H_TRACE") != nullptr;  // host-side phases of a pipelined call, to stderr
     const auto tr_t0 = std::chrono::steady_clock::now();
+    // (calls of several contexts on one clock; with the trace on, a reference event ties the device's clock to it)
+    static const auto epoch = std::chrono::steady_clock::now();
+    static hipEvent_t tr_ref = nullptr;
+    static double tr_ref_host_us = 0;
+    static std::mutex tr_mu;
+    if (h2h_trace) {
+        std::lock_guard<std::mutex> lkt(tr_mu);
+        if (!tr_ref && hipEventCreate(&tr_ref) == hipSuccess) {
+            (void)hipEventRecord(tr_ref, ctx->stream);
+            (void)hipEventSynchronize(tr_ref);
+            tr_ref_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch).count();
+        }
+        for (auto &row : ctx->tr_ev)
+            for (hipEvent_t &e : row)
+                if (!e) (void)hipEventCreate(&e);
+    }
+    auto tr_rec = [&](int k, int i, hipStream_t s) {
+        if (h2h_trace && ctx->tr_ev[k][i]) (void)hipEventRecord(ctx->tr_ev[k][i], s);
+    };
     auto tr = [&](const char *what) {
         if (h2h_trace) {
-            static const auto epoch = std::chrono::steady_clock::now();  // (calls of several contexts on one clock)
             const auto now = std::chrono::steady_clock::now();
             std::fprintf(stderr, "h2h ctx %p at %9.1f us, %8.1f us into the call: %s\n", (void *)ctx,
                          std::chrono::duration<double, std::micro>(now - epoch).count(),
@@ -1545,7 +1632,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     if (const char *v = tuning_env("RSASA_SUB_ATOMS")) kSubAtoms = (size_t)std::max(100000, std::atoi(v));
     std::vector<size_t> cut{0};        // structure indices where sub-batches begin / end
     if (N >= 2 * kSubAtoms && n_structures > 1) {
-        size_t max_sub = 8;
+        // (a worker of a stream of host batches: the NEXT call's uploads hide a call's fill and drain, so two sub-batches
+        // - one upload running beside one half's kernels - are enough, and every sub-batch fewer is a grid build fewer
+        // between the occlusion kernels: HostStream)
+        size_t max_sub = ctx->stream_sub_batches ? ctx->stream_sub_batches : 8;
         if (const char *v = tuning_env("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
         const size_t n_sub = std::min<size_t>(max_sub, N / kSubAtoms);
         // The link is the longest leg.  The first sub-batch's upload is not hidden behind anything, and nothing hides
@@ -1660,7 +1750,18 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     if ((fold_ids || code_radii) && !ctx->fold_pool) {
         unsigned nt = std::thread::hardware_concurrency() / 4;
         if (const char *v = tuning_env("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
-        ctx->fold_pool = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)), ctx->node);
+        // ONE pool per device for all its contexts: two contexts with a stream of host batches between them (or
+        // process_files' pair) would otherwise run two pools of sixteen threads against each other - under a CPU quota
+        // (the measurement boxes: 16 CPUs) both are throttled, a sub-batch's coding takes 8 ms instead of 1 and its upload
+        // waits for it.  Jobs are worked off in the order they were submitted, whoever submitted them.
+        static std::mutex pools_mu;
+        static FoldPool *pools[64] = {};
+        {
+            std::lock_guard<std::mutex> lkp(pools_mu);
+            const int d = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+            if (!pools[d]) pools[d] = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)), ctx->node);  // (lives as long as the process)
+            ctx->fold_pool = pools[d];
+        }
         if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
     }
     std::vector<unsigned long long> fold_job(cut.size(), 0);
@@ -1842,7 +1943,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must be non-decreasing");
     if (structure_offsets[0] != 0) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must span [0, n_atoms]");
     hipStream_t cp = ctx->copy_stream;
-    if (!ctx->stream2) RS_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    if (!ctx->stream2) RS_HIP(ctx, new_stream(ctx, &ctx->stream2, 2));
     for (int attempt = 0;; attempt++) {
         uint64_t need_cells = 0;
         int err = RSASA_OK;
@@ -1883,11 +1984,13 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 check(k);
                 if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
             }
+            tr_rec(k, 0, cp);
             if ((rc = upload_xyz(c, cp))) return rc;
             if (fold_ids || code_radii) ctx->fold_pool->wait(fold_job[c]);
             use_codes[c] = code_radii && !ctx->radius_codec.failed.load();
             if (c == 0) tr("first sub-batch coded");
             if ((rc = upload(c, cp))) return rc;
+            tr_rec(k, 1, cp);
             RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
             // consecutive sub-batches alternate between the context's two workspaces and launch streams: a
             // sub-batch's grid build is then queued beside its predecessor's occlusion kernel and starts in its tail
@@ -1920,7 +2023,9 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             pd.n_points = n_points;
             pd.stream = st;
             pd.ws = w;
+            tr_rec(k, 2, st);
             if ((rc = enqueue_batch(ctx, pd, ctx->slot[k]))) return rc;
+            tr_rec(k, 3, st);
             RS_HIP(ctx, hipEventRecord(ctx->ev_done[k], st));
             RS_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_done[k], 0));
             if ((rc = copy_out(c))) return rc;
@@ -1937,6 +2042,15 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         }
         RS_HIP(ctx, hipStreamSynchronize(dn));
         tr("all done");
+        if (h2h_trace && tr_ref && n_sub <= (size_t)kSlots) {
+            // the device's side of the same call: each sub-batch's uploads and kernels on the host trace's clock
+            for (size_t c = 0; c < n_sub; c++) {
+                float t[4] = {};
+                for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&t[i], tr_ref, ctx->tr_ev[c][i]);
+                std::fprintf(stderr, "h2h ctx %p device: sub-batch %zu uploads %9.1f .. %9.1f us, kernels %9.1f .. %9.1f us\n", (void *)ctx, c,
+                             tr_ref_host_us + t[0] * 1e3, tr_ref_host_us + t[1] * 1e3, tr_ref_host_us + t[2] * 1e3, tr_ref_host_us + t[3] * 1e3);
+            }
+        }
         if (err) return err;
         if (!need_cells) return RSASA_OK;
         if (need_cells >= 0xFFFFFFF0ull || attempt >= 3)
@@ -1990,10 +2104,14 @@ static void host_stream_worker(HostStream *hs, int w)
             const uint32_t hint = hs->sub[w]->tuning.deferred_hint;  // (what this context has learnt stays its own)
             hs->sub[w]->tuning = job->tuning;
             hs->sub[w]->tuning.deferred_hint = hint;
+            hs->sub[w]->stream_sub_batches = hs->sub_batches;
+            hs->sub[w]->link_gate = &hs->gate;
+            hs->sub[w]->link_ticket = job->ticket;
         }
         const int rc = rsasa_calculate_sasa_batch(hs->sub[w], job->x, job->y, job->z, job->radius, job->id, job->structure_offsets,
                                                   job->n_structures, job->probe, job->n_points, job->out_atom,
                                                   job->residue_offsets, job->n_residues, job->out_res);
+        hs->gate.advance(job->ticket);  // (a call that never took the link: a small batch, an error)
         std::string msg = rc ? rsasa_context_last_error(hs->sub[w]) : "";
         {
             std::lock_guard<std::mutex> lk(hs->mu);
@@ -2018,15 +2136,21 @@ int rsasa_host_batch_enqueue(rsasa_context_t *ctx, const float *x, const float *
         if (!ctx->host_stream) {
             hs = new (std::nothrow) HostStream();
             if (!hs) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "host stream");
-            for (int w = 0; w < HostStream::kWorkers; w++) {
-                rc = rsasa_context_create(ctx->device, &hs->sub[w]);
+            if (const char *v = tuning_env("RSASA_STREAM_WORKERS")) hs->n_workers = std::min((int)HostStream::kMaxWorkers, std::max(1, std::atoi(v)));
+            for (int w = 0; w < hs->n_workers; w++) {
+                int own = 2;
+                if (const char *v = tuning_env("RSASA_OWN_QUEUES")) own = std::atoi(v);
+                rc = context_create(ctx->device, own, &hs->sub[w]);
                 if (rc) {
                     for (rsasa_context *sc : hs->sub) rsasa_context_destroy(sc);
                     delete hs;
                     return fail(ctx, rc, "rsasa_context_create (host stream worker)");
                 }
             }
-            for (int w = 0; w < HostStream::kWorkers; w++) hs->th[w] = std::thread(host_stream_worker, hs, w);
+            {
+                hs->sub_batches = 2;
+            }
+            for (int w = 0; w < hs->n_workers; w++) hs->th[w] = std::thread(host_stream_worker, hs, w);
             ctx->host_stream = hs;
         }
         hs = ctx->host_stream;
@@ -2049,6 +2173,7 @@ int rsasa_host_batch_enqueue(rsasa_context_t *ctx, const float *x, const float *
         hs->cv_done.wait(lk, [&] { return hs->jobs.size() < HostStream::kMaxQueued || hs->jobs.front()->done; });
         if (hs->jobs.size() >= HostStream::kMaxQueued)
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "too many host batches enqueued and not waited for (rsasa_host_batch_wait)");
+        job->ticket = hs->next_ticket++;
         hs->jobs.push_back(job);
     }
     hs->cv_work.notify_all();

@@ -19,18 +19,20 @@ args = [a for a in sys.argv[1:] if a != "--api"]
 steps = int(args[0]) if args else 12
 if api:
     with rustsasa_amd.Context(0) as ctx:
-        outs = [pin(np.zeros(b.n_residues, np.float32)) for _ in range(2)]
+        depth = int(os.environ.get("H2H_DEPTH", "3"))  # host batches in flight
+        outs = [pin(np.zeros(b.n_residues, np.float32)) for _ in range(depth)]
         def enq(k):
-            ctx.host_batch_enqueue(x, y, z, r, ids, b.structure_offsets, 1.4, 100, residue_offsets=ro, want_atoms=False, res_out=outs[k % 2])
-        for rep in range(2):
+            ctx.host_batch_enqueue(x, y, z, r, ids, b.structure_offsets, 1.4, 100, residue_offsets=ro, want_atoms=False, res_out=outs[k % depth])
+        for rep in range(int(os.environ.get("H2H_REPS", "2"))):
             t0 = time.perf_counter()
-            enq(0)
-            for k in range(1, steps):
+            for k in range(min(depth - 1, steps)):
+                enq(k)
+            for k in range(depth - 1, steps):
                 enq(k)
                 ctx.host_batch_wait()
-            ctx.host_batch_wait()
+            ctx.host_batch_wait_all()
             dt = (time.perf_counter() - t0) / steps
-            print(f"stream API, {steps} batches: {dt * 1e3:.3f} ms per proteome batch, {b.n_structures / dt:.0f} structures/s, outputs equal {np.array_equal(outs[0], outs[1])}", flush=True)
+            print(f"stream API, {steps} batches: {dt * 1e3:.3f} ms per proteome batch, {b.n_structures / dt:.0f} structures/s, outputs equal {all(np.array_equal(outs[0], o) for o in outs)}", flush=True)
     sys.stdout.flush()
     sys.exit(0)
 for T in (1, 2, 3):

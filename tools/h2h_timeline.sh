@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/h2h_trace
 export H2H_SORTED=1  # bench.py's order: largest structures first
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/h2h_trace -- python3 tools/bench_h2h.py 8 > /dev/null 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/h2h_trace -- python3 tools/bench_h2h.py ${1:-8} > /dev/null 2>&1
 python3 - <<'P'
 import csv, glob, re
 kt = glob.glob("gpurun_out/h2h_trace/**/*kernel_trace.csv", recursive=True)[0]
