@@ -1051,7 +1051,9 @@ static int context_create(int device, int own_queues, rsasa_context_t **out_ctx)
 
 int rsasa_context_create(int device, rsasa_context_t **out_ctx)
 {
-    return context_create(device, 0, out_ctx);
+    int own = 0;
+    if (const char *v = tuning_env("RSASA_CTX_OWN_QUEUES")) own = std::atoi(v);  // (experiment: DESIGN.md 6)
+    return context_create(device, own, out_ctx);
 }
 
 static int context_create(int device, int own_queues, rsasa_context_t **out_ctx)

@@ -45,7 +45,8 @@ python3 bench.py --shard-of 8 > $out/shard8.log 2>&1; tail -1 $out/shard8.log > 
 python3 tools/bench_two_in_flight.py 1 8 2>&1 | grep "^shard" > $out/two_in_flight.txt
 python3 bench.py > $out/bench2.log 2>&1; tail -1 $out/bench2.log > $out/bench_run2.json
 tools/microbench_clock > $out/microbench_clock.txt 2>&1
-python3 tools/bench_h2h_stream.py --api 12 2>/dev/null | tail -1 > $out/h2h_stream.txt
-python3 tools/bench_h2h.py 8 2>/dev/null | tail -1 >> $out/h2h_stream.txt
+H2H_REPS=5 python3 tools/bench_h2h_stream.py --api 12 2>/dev/null | tail -3 > $out/h2h_stream.txt
+H2H_SORTED=1 python3 tools/bench_h2h.py 8 2>/dev/null | tail -1 >> $out/h2h_stream.txt
+python3 tools/h2h_stream_trace.py 12 3 2> $out/h2h_trace.log > /dev/null; awk '/==== round 2/,0' $out/h2h_trace.log | grep "device:\|====" > $out/h2h_stream_trace.txt
 rm -rf $out/trace $out/pmc_a $out/pmc_b $out/pmc_c $out/pmc_d $out/pmc_e $out/pmc_g $out/pmc_fetch $out/pmc_write $out/pmc_tcc
 ls -la $out; cat $out/bench.json; cat $out/bench_under_rocprof.json; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc.txt

@@ -16,7 +16,7 @@ dst = os.path.join(ROOT, "profiles")
 names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
                                         "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json", "pmc_uniform1m.txt",
                                         "files_mode_1500.json", "files_mode_cif.json", "bench_shard_of_8.json", "two_in_flight.txt", "bench_run2.json",
-                                        "microbench_clock.txt", "h2h_stream.txt")}
+                                        "microbench_clock.txt", "h2h_stream.txt", "h2h_stream_trace.txt")}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 10:
