@@ -820,6 +820,12 @@ def main():
                        "grid_cells_rank0": cells[0],
                        "atoms_per_s": round(total_atoms * args.steps / elapsed, 1),
                        "ids": not args.no_ids,
+                       "ids_note": "one 64-bit id per atom is passed, as the reference's Atom carries one; they increase "
+                                   "within every structure (indices, as the reference's callers set them), the engine's "
+                                   "check finds that (k_bounds on the device, the coding threads on the host) and runs "
+                                   "the batches without them - same values (parity below is against the oracle WITH the "
+                                   "ids); rsasa_context_ids_dropped counts the (sub-)batches",
+                       "ids_dropped_batches": ctx.ids_dropped(),
                        "numa_node": numa["numa_node"], "cpus": numa["cpus"], "cpu_list": numa["cpu_list"],
                        "gpu_pci": numa["gpu_pci"],
                        "parallelism": f"{world} rank(s), one per GPU, independent shards, no data-path "

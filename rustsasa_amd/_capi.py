@@ -89,6 +89,7 @@ SYMBOLS = {
     "rsasa_context_clone_settings": (C.c_int, [_vp, _vp]),
     "rsasa_context_enable_timing": (C.c_int, [_vp, C.c_int]),
     "rsasa_context_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
+    "rsasa_context_ids_dropped": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "rsasa_sphere_points": (C.c_int, [C.c_size_t, _vp, _vp, _vp]),
 }
 

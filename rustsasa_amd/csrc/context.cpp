@@ -191,6 +191,7 @@ struct Pending {
     const uint8_t *radius8 = nullptr;     // nullable (pipelined host path): one-byte radius codes + their table
     const float *radius_table = nullptr;  // (BatchView::radius8); batch.radius is then not read
     int ws = 0;                      // the workspace (and host slot) the batch runs in
+    bool ids_needed_known = false;   // the host has checked the ids itself and found that they matter (BatchView::ids_check off)
 };
 
 // The distinct radii of a host batch, collected while worker threads turn the radii into one-byte codes: a
@@ -220,6 +221,16 @@ struct RadiusCodec {
     }
 };
 
+// What tells whether a batch's ids matter: they do not if the ids of every structure increase strictly (atom serials,
+// indices) - then they are all different, and "a neighbour with the atom's own id" (lib.rs:127) is the atom itself.
+// starts[0 .. n_starts] are the structures' first atoms, in the numbering of src's entries (src[0] is atom `first`).
+struct IdOrder {
+    const uint32_t *starts = nullptr;
+    size_t n_starts = 0;
+    uint32_t first = 0;
+    std::atomic<int> *ids_matter = nullptr;  // set to 1 by a worker that finds an id not above its predecessor's
+};
+
 // A few worker threads that fold 64-bit ids to 32 bits (device_utils.h fold_id) ahead of the uploads: the
 // pipelined host path then moves 4 bytes per id over the link instead of 8.  Jobs (one per sub-batch) are
 // worked off in the order they were submitted, every worker taking blocks of the current job.
@@ -241,13 +252,13 @@ public:
         cv.notify_all();
         for (auto &w : workers) w.join();
     }
-    // queues folding src[0 .. n) into dst (either may be null) and coding rad[0 .. n) into rad8 (if codec is set);
-    // returns the job's number for wait()
+    // queues folding src[0 .. n) into dst (either may be null), coding rad[0 .. n) into rad8 (if codec is set) and
+    // checking the order of src (if order.ids_matter is set); returns the job's number for wait()
     unsigned long long submit(const uint64_t *src, uint32_t *dst, size_t n, const float *rad = nullptr, uint8_t *rad8 = nullptr,
-                              RadiusCodec *codec = nullptr)
+                              RadiusCodec *codec = nullptr, IdOrder order = IdOrder())
     {
         std::lock_guard<std::mutex> lk(mu);
-        jobs.push_back(Job{src, dst, n, 0, 0, rad, rad8, codec});
+        jobs.push_back(Job{src, dst, n, 0, 0, rad, rad8, codec, order});
         cv.notify_all();
         return first_job + jobs.size() - 1;
     }
@@ -266,6 +277,7 @@ private:
         const float *rad;
         uint8_t *rad8;
         RadiusCodec *codec;
+        IdOrder order;
     };
     void run()
     {
@@ -280,8 +292,21 @@ private:
             const float *rad = j.rad;
             uint8_t *rad8 = j.rad8;
             RadiusCodec *codec = j.codec;
+            const IdOrder order = j.order;
             const size_t b = blk * kBlock, e = std::min(j.n, b + kBlock);
             lk.unlock();
+            if (s && order.ids_matter && !order.ids_matter->load(std::memory_order_relaxed)) {
+                for (size_t i = std::max<size_t>(b, 1); i < e; i++) {
+                    if (s[i] > s[i - 1]) continue;
+                    // (rare: a structure's first atom - serials start over - or ids that do matter)
+                    const uint32_t atom = order.first + (uint32_t)i;
+                    const uint32_t *hit = std::lower_bound(order.starts, order.starts + order.n_starts, atom);
+                    if (hit == order.starts + order.n_starts || *hit != atom) {
+                        order.ids_matter->store(1, std::memory_order_relaxed);
+                        break;
+                    }
+                }
+            }
             if (s && d)
                 for (size_t i = b; i < e; i++) d[i] = (uint32_t)s[i] ^ ((uint32_t)(s[i] >> 32) * 0x9E3779B1u);  // fold_id
             if (codec && !codec->failed.load(std::memory_order_relaxed)) {
@@ -464,7 +489,9 @@ struct rsasa_context {
         BatchStatus *h_status = nullptr;
         uint32_t *h_res = nullptr;      // rebased residue offsets of a sub-batch (a pageable source would
         size_t h_res_cap = 0;           // make the "asynchronous" upload wait for the copy stream)
+        bool ids_check = false;         // the batch that last used the slot ran with BatchView::ids_check
     } slot[kSlots];
+    std::atomic<uint64_t> ids_dropped{0};         // batches / sub-batches that ran without their ids (rsasa_context_ids_dropped)
     hipEvent_t ev_done[kSlots] = {};              // all work of the sub-batch in slot k has been executed
     uint64_t cell_capacity = 0;
 
@@ -798,7 +825,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
             const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
             has_tail |= e - b >= kLdsMaxAtoms;
             for (uint32_t a = b; a < e; a += kSegmentAtoms)
-                hs.h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms)};
+                hs.h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms), a != b ? 1u : 0u};
         }
     }
 
@@ -840,6 +867,10 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     BatchView v{};
     v.x = bt.x; v.y = bt.y; v.z = bt.z; v.radius = bt.radius; v.id = bt.id;
     v.id32 = pd.id32;
+    // ids that are all different within their structure change nothing: checked on the device (BatchView::ids_check)
+    // unless the host has looked already (pd.ids_needed_known: the host paths check before they upload)
+    v.ids_check = (has_id && !pd.id32 && !pd.ids_needed_known && !keep_ids && !tuning_env("RSASA_NO_ID_CHECK")) ? 1u : 0u;
+    hs.ids_check = v.ids_check != 0u;
     v.radius8 = pd.radius8;
     v.radius_table = pd.radius_table;
     v.residue_offsets = bt.residue_offsets;
@@ -950,6 +981,7 @@ int wait_one(rsasa_context *ctx, Pending &pd)
         }
         if (!stt.overflow) {
             ctx->tuning.deferred_hint = stt.deferred;  // (sizes the next batch's launch over its deferred list)
+            if (ctx->slot[pd.ws].ids_check && !stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             if (ctx->timing) {
                 float g = 0, o = 0, a = 0, t = 0;
                 (void)hipEventElapsedTime(&g, W.ev[0], W.ev[1]);
@@ -1295,6 +1327,20 @@ int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out)
     if (!ctx->timings_valid)
         return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "no timed batch has completed");
     *out = ctx->timings;
+    return RSASA_OK;
+}
+
+int rsasa_context_ids_dropped(rsasa_context_t *ctx, uint64_t *out_batches)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (!out_batches) return RSASA_ERR_INVALID_ARGUMENT;
+    uint64_t n = ctx->ids_dropped.load(std::memory_order_relaxed);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (ctx->host_stream)  // (the stream's batches run on its workers' contexts)
+        for (int w = 0; w < ctx->host_stream->n_workers; w++)
+            if (ctx->host_stream->sub[w]) n += ctx->host_stream->sub[w]->ids_dropped.load(std::memory_order_relaxed);
+    *out_batches = n;
     return RSASA_OK;
 }
 
@@ -1729,9 +1775,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             Pack &pk = pack[c];
             pk.base = total;
             pk.o_res = kTableWords * 4;
-            pk.o_id = pk.o_res + up16(want_res ? (nr + 1) * 4 : 0);
-            pk.o_r8 = pk.o_id + up16(fold_ids ? na * 4 : 0);
-            pk.bytes = pk.o_r8 + up16(code_radii ? na : 0);
+            // (the folded ids last: a sub-batch whose ids turn out not to matter is uploaded without them)
+            pk.o_r8 = pk.o_res + up16(want_res ? (nr + 1) * 4 : 0);
+            pk.o_id = pk.o_r8 + up16(code_radii ? na : 0);
+            pk.bytes = pk.o_id + up16(fold_ids ? na * 4 : 0);
             total += pk.bytes;
             largest = std::max(largest, pk.bytes);
         }
@@ -1749,7 +1796,17 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             ctx->h_pack_cap = cap;
         }
     }
-    if ((fold_ids || code_radii) && !ctx->fold_pool) {
+    // Ids that are all different within their structure change nothing (BatchView::ids_check).  The pipelined path's
+    // coding workers look while they fold; one large sub-batch is checked by the same workers while its coordinates
+    // cross the link (then its 8 bytes of id per atom stay on the host); anything smaller is checked on the device.
+    const bool check_ids = id && !tuning_env("RSASA_NO_ID_CHECK");
+    bool host_check = false;
+    if (!piped && check_ids && cut.size() == 2 && structure_offsets[n_structures] >= 262144u && n_points >= 1 && n_points <= (1u << 24)) {
+        Lattice lat_probe;
+        host_check = get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
+                     occlusion_uses_mx(ctx->tuning, lat_probe, structure_offsets[n_structures]);
+    }
+    if ((fold_ids || code_radii || host_check) && !ctx->fold_pool) {
         unsigned nt = std::thread::hardware_concurrency() / 4;
         if (const char *v = tuning_env("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
         // ONE pool per device for all its contexts: two contexts with a stream of host batches between them (or
@@ -1821,6 +1878,11 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         if ((rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
     tr("setup done");
     std::vector<char> use_codes(cut.size(), 0);  // sub-batch c's radii travel as codes (decided once its coding job is done)
+    // sub-batch c's ids stay on the host: those of each of its structures increase strictly, so they are all different and
+    // change nothing (IdOrder; found by the workers that fold them)
+    std::vector<char> drop_ids(cut.size(), 0);
+    std::unique_ptr<std::atomic<int>[]> ids_matter(new (std::nothrow) std::atomic<int>[cut.size()]);
+    if (!ids_matter) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "id flags");
     // the coordinates of a sub-batch do not wait for its coding job (ids, radius codes): they are queued first, and the
     // first sub-batch's start crossing the link while its block is still being written
     auto upload_xyz = [&](size_t c, hipStream_t st) -> int {
@@ -1843,7 +1905,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         for (size_t i = s0; i <= s1; i++) so[k][i - s0] = structure_offsets[i] - (uint32_t)a0;
         if (na) {
             if (!use_codes[c]) RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
-            if (!fold_ids && id) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
+            if (!fold_ids && id && !drop_ids[c]) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
         }
         if (piped) {
             // the sub-batch's pinned block (the workers have filled in ids and radius codes): table and offsets, one copy
@@ -1854,7 +1916,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 uint32_t *ro = reinterpret_cast<uint32_t *>(blk + pack[c].o_res);
                 for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
             }
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_pack[k].p, blk, pack[c].bytes, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_pack[k].p, blk, drop_ids[c] ? pack[c].o_id : pack[c].bytes, hipMemcpyHostToDevice, st));
         } else if (want_res) {
             const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
             uint32_t *ro = ctx->slot[k].h_res;
@@ -1872,7 +1934,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         bt.y = dev_y[k];
         bt.z = dev_z[k];
         bt.radius = (const float *)br[k]->p;
-        bt.id = id ? (const uint64_t *)bi[k]->p : nullptr;
+        bt.id = id && !drop_ids[c] ? (const uint64_t *)bi[k]->p : nullptr;
         bt.structure_offsets_host = so[k].data();
         bt.n_structures = s1 - s0;
         bt.n_atoms = na;
@@ -1917,7 +1979,23 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
     };
     if (!piped) {
         // one sub-batch: upload, kernels, wait (re-runs with a larger cell array if needed), copy out
+        unsigned long long order_job = 0;
+        if (host_check) {
+            IdOrder order;
+            ids_matter[0].store(0);
+            order.starts = structure_offsets;
+            order.n_starts = n_structures;
+            order.ids_matter = &ids_matter[0];
+            order_job = ctx->fold_pool->submit(id, nullptr, structure_offsets[n_structures], nullptr, nullptr, nullptr, order);
+            fold_drain.pool = ctx->fold_pool;
+            fold_drain.last = order_job;
+        }
         if ((rc = upload_xyz(0, st))) return rc;
+        if (host_check) {
+            ctx->fold_pool->wait(order_job);
+            drop_ids[0] = !ids_matter[0].load();
+            if (drop_ids[0]) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+        }
         if ((rc = upload(0, st))) return rc;
         if ((rc = enqueue(0))) return rc;
         const size_t na = structure_offsets[cut[1]], nr = want_res ? res_cut[1] : 0;
@@ -1958,6 +2036,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 err = fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius + max radius must be a positive finite number");
             if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
             else ctx->tuning.deferred_hint = stt.deferred;
+            if (!stt.overflow && ctx->slot[k].ids_check && !stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
         };
         bool used[kSlots] = {};
         if (fold_ids || code_radii) {
@@ -1967,10 +2046,18 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             for (size_t c = 0; c < n_sub; c++) {
                 const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
                 char *blk = ctx->h_pack + pack[c].base;
+                IdOrder order;
+                ids_matter[c].store(0);
+                if (fold_ids && check_ids) {
+                    order.starts = structure_offsets + cut[c];
+                    order.n_starts = cut[c + 1] - cut[c];
+                    order.first = (uint32_t)a0;
+                    order.ids_matter = &ids_matter[c];
+                }
                 fold_job[c] = ctx->fold_pool->submit(fold_ids ? id + a0 : nullptr,
                                                      fold_ids ? reinterpret_cast<uint32_t *>(blk + pack[c].o_id) : nullptr, na,
                                                      radius + a0, code_radii ? reinterpret_cast<uint8_t *>(blk + pack[c].o_r8) : nullptr,
-                                                     code_radii ? &ctx->radius_codec : nullptr);
+                                                     code_radii ? &ctx->radius_codec : nullptr, order);
             }
             fold_drain.pool = ctx->fold_pool;
             fold_drain.last = fold_job[n_sub - 1];
@@ -1990,6 +2077,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             if ((rc = upload_xyz(c, cp))) return rc;
             if (fold_ids || code_radii) ctx->fold_pool->wait(fold_job[c]);
             use_codes[c] = code_radii && !ctx->radius_codec.failed.load();
+            drop_ids[c] = fold_ids && check_ids && !ids_matter[c].load();
+            if (drop_ids[c]) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             if (c == 0) tr("first sub-batch coded");
             if ((rc = upload(c, cp))) return rc;
             tr_rec(k, 1, cp);
@@ -2008,9 +2097,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             pd.batch.y = dev_y[k];
             pd.batch.z = dev_z[k];
             pd.batch.radius = (const float *)br[k]->p;
-            pd.batch.id = fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
+            pd.batch.id = drop_ids[c] ? nullptr : fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
             const char *dblk = (const char *)ctx->in_pack[k].p;
-            pd.id32 = fold_ids ? (const uint32_t *)(dblk + pack[c].o_id) : nullptr;
+            pd.id32 = fold_ids && !drop_ids[c] ? (const uint32_t *)(dblk + pack[c].o_id) : nullptr;
+            pd.ids_needed_known = fold_ids && check_ids && !drop_ids[c];
             pd.batch.structure_offsets_host = so[k].data();
             pd.batch.n_structures = s1 - s0;
             pd.batch.n_atoms = na;

@@ -22,7 +22,7 @@ namespace {
 
 // ------------------------------------------------------ per-structure grid --
 
-__global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *status)
+__global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *status, uint32_t ids_needed)
 {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s == 0) {
@@ -35,6 +35,7 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
         status->tail_atom_base = 0;
         status->n_windows = 0;
         status->grid_cells = 0;
+        status->ids_needed = ids_needed;  // (0 with BatchView::ids_check: k_bounds raises it)
     }
     if (s >= n_structures) return;
     const int pinf = f2ord(__int_as_float(0x7F800000)), ninf = f2ord(__int_as_float(0xFF800000));
@@ -58,6 +59,13 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     float mxx = __int_as_float(0xFF800000), mxy = mxx, mxz = mxx;
     float mr = 0.0f;
     bool odd_r = false;  // a radius outside [0, 64] (or NaN), a coordinate beyond 1e8 (or NaN / infinite): see StructGrid::odd_radii
+    if (b.ids_check) {
+        // BatchView::ids_check: an id that is not larger than its predecessor's in the same structure
+        bool falls = false;
+        for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x)
+            if (i > seg.begin || seg.continues) falls |= b.id[i] <= b.id[i - 1u];
+        if (falls) b.status->ids_needed = 1u;
+    }
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
         float x = b.x[i], y = b.y[i], z = b.z[i], r = load_radius(b.radius, b.radius8, b.radius_table, i);
         odd_r |= !(r >= 0.0f && r <= 64.0f) | !(fmaxf(fmaxf(fabsf(x), fabsf(y)), fabsf(z)) <= 1e8f) | (x != x) | (y != y) | (z != z);
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(sort_window_threads(SINGLE), SINGLE ? 4 : (RSASA_SO
     auto pr = [&](uint32_t i) { return load_radius(b.radius, b.radius8, b.radius_table, i); };
     const uint32_t *__restrict__ pid32 = b.id32;
     const uint64_t *__restrict__ pid = pid32 ? reinterpret_cast<const uint64_t *>(pid32) : b.id;  // (non-null: the batch has ids)
+    if (!SINGLE && b.ids_check && b.status->ids_needed == 0u) pid = nullptr;  // (all different: as good as none)
     uint32_t *__restrict__ rank_of = b.rank_of;  // sorted position of the atoms without a slot
     uint4 *stage = reinterpret_cast<uint4 *>(s_cnt);
     // ---- the structure's first kSlots * 1024 atoms (slot k of a thread: atom a0 + tid + 1024 k) ----
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
         b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], load_radius(b.radius, b.radius8, b.radius_table, i));
         b.sorted_orig[pos] = i;
         b.sid_sorted[pos] = s;
-        if (b.sorted_id32) { const uint64_t v = load_id(b.id, b.id32, i); if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
+        if (b.sorted_id32 && !(b.ids_check && b.status->ids_needed == 0u)) { const uint64_t v = load_id(b.id, b.id32, i); if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
     }
 }
 
@@ -733,7 +742,7 @@ __global__ __launch_bounds__(256) void k_residue_sums(BatchView b)
 void launch_grid_prepare(const BatchView &b, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_init_acc, dim3(cdiv(b.n_structures > 0 ? b.n_structures : 1, 256)), dim3(256), 0, stream,
-                       b.acc, b.n_structures, b.status);
+                       b.acc, b.n_structures, b.status, b.ids_check ? 0u : 1u);
     if (b.n_segments)
         hipLaunchKernelGGL(k_bounds, dim3(b.n_segments), dim3(256), 0, stream, b);
     const uint32_t n_parts = cdiv(b.n_structures > 0 ? b.n_structures : 1, 256);

@@ -105,6 +105,13 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
     const uint32_t resident = device_cus() * (NW == 4 ? 7u : NW == 8 ? 3u : 2u);
     const uint32_t n_blocks = mx_persistent(MULTI) ? min(cdiv(n_atoms, NW * a3.atoms_per_wave), resident) : cdiv(n_atoms, NW * a3.atoms_per_wave);
     if (mx_persistent(MULTI)) (void)hipMemsetAsync(a3.claim, 0, 8u * kClaimStride * 4u, stream);  // (a failure shows as the launch's)
+    if (has_id && a3.ids_check) {
+        // BatchView::ids_check: whether the ids matter is known on the device only - both instantiations are launched, the
+        // one that BatchStatus::ids_needed does not ask for returns at once (its workgroups touch nothing, the claim
+        // counters included)
+        if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+        else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+    }
     if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
     else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
     else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);

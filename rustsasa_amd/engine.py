@@ -272,6 +272,13 @@ class Context:
         self._check(self._lib.rsasa_context_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timings._fields_}
 
+    def ids_dropped(self) -> int:
+        """(Sub-)batches that ran without their ids because the ids of every structure increased strictly
+        (rsasa_context_ids_dropped)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.rsasa_context_ids_dropped(self._h, C.byref(n)))
+        return int(n.value)
+
 
 def make_atoms(x, y, z, radius, ids) -> np.ndarray:
     """Packs SoA columns into rsasa_atom_t records."""

@@ -65,6 +65,8 @@ int main(void)
         if (rsasa_host_batch_enqueue(ctx, x, y, z, rad, NULL, so, 1, 1.4f, 5000, a2, NULL, 0, NULL) != RSASA_OK) return 33;
         if (rsasa_host_batch_wait(ctx) != RSASA_OK || a1[0] != out[0] || a1[2] != out[2]) return 34;
         if (rsasa_host_batch_wait_all(ctx) != RSASA_OK || a2[1] != out[1]) return 35;
+        uint64_t dropped = 99;
+        if (rsasa_context_ids_dropped(ctx, &dropped) != RSASA_OK || dropped != 0) return 36;  /* (small batches are not checked) */
     }
     /* empty input is valid and touches nothing */
     if (rsasa_calculate_sasa_internal(ctx, NULL, 0, 1.4f, 100, 1, NULL) != RSASA_OK) return 20;

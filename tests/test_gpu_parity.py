@@ -1041,6 +1041,119 @@ def test_duplicate_ids_in_device_batches():
         assert np.array_equal(atom, want)
 
 
+def _id_variants(b, rng):
+    """Id columns for the check that drops ids which cannot matter (BatchView::ids_check / IdOrder): ones that pass
+    it, ones that fail it in a single place - inside a structure, on a 4 096-atom seam of the bounds kernel, on a
+    65 536-atom seam of the host's coding blocks - and ones that pass although they fall at every structure's start.
+    Returns the columns and the names of those whose repeated id changes a value (most atoms are buried)."""
+    n, so = b.n_atoms, b.structure_offsets.astype(np.int64)
+    sizes = np.diff(so)
+    rising = np.arange(n, dtype=np.uint64) * 3 + 10
+    per_structure = np.concatenate([np.arange(m, dtype=np.uint64) for m in sizes])  # serials start over: still all different
+    out = {"rising": rising, "per_structure": per_structure, "falling": rising[::-1].copy()}
+    sensitive = set()
+    base_of = {}
+
+    def with_pair(at):
+        """Atom `at` takes the id of an EARLIER atom of its structure, so the ids fall exactly at `at` - one within reach,
+        and if the oracle says so, one whose absence among `at`'s neighbours changes a value."""
+        k = int(np.searchsorted(so, at, side="right") - 1)
+        s0, s1 = int(so[k]), int(so[k + 1])
+        cols = (b.x[s0:s1], b.y[s0:s1], b.z[s0:s1], b.radius[s0:s1])
+        if k not in base_of:
+            base_of[k] = po.calculate_sasa_internal(*cols, None, PROBE, 100, 8)
+        d2 = (b.x[s0:at] - b.x[at]) ** 2 + (b.y[s0:at] - b.y[at]) ** 2 + (b.z[s0:at] - b.z[at]) ** 2
+        ids = rising.copy()
+        for j in np.argsort(d2)[:8]:
+            ids[at] = rising[s0 + int(j)]
+            if not np.array_equal(po.calculate_sasa_internal(*cols, ids[s0:s1], PROBE, 100, 8), base_of[k]):
+                return ids, True
+        return ids, False
+
+    def first_that_shows(name, candidates):
+        ids = None
+        for at in candidates:
+            ids, shows = with_pair(int(at))
+            if shows:
+                sensitive.add(name)
+                break
+        if ids is not None:
+            out[name] = ids
+
+    s0, s1 = int(so[1]), int(so[2])
+    base1 = po.calculate_sasa_internal(b.x[s0:s1], b.y[s0:s1], b.z[s0:s1], b.radius[s0:s1], None, PROBE, 100, 8)
+    first_that_shows("pair_inside", [s0 + int(i) for i in np.flatnonzero(base1 > 5.0) if i > 50][:10])
+    first_that_shows("pair_on_bounds_seam", [int(so[k]) + seam for k in np.flatnonzero(sizes > 4200)[:6]
+                                             for seam in (4096, 8192) if seam + 50 < sizes[k]])
+    if n > 70000:
+        first_that_shows("pair_on_block_seam", [65536 if 65536 not in so else 65537])
+    first_that_shows("pair_at_the_very_end", [n - 1])
+    eq_across = rising.copy()                        # the last atom of a structure and the first of the next: not a pair
+    eq_across[so[2]] = eq_across[so[2] - 1]
+    out["equal_across_structures"] = eq_across
+    return out, sensitive
+
+
+def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch):
+    """Ids only matter where two atoms of one structure share one (lib.rs:127).  The engine checks whether the ids of
+    every structure increase strictly and runs such a batch as one without ids; a single repeated id anywhere must keep
+    the ids in play.  Device-resident batches (checked by k_bounds), one large host sub-batch (checked by the coding
+    workers while the coordinates upload) and pipelined host batches (checked per sub-batch while the ids are folded),
+    every atom against the oracle."""
+    import rustsasa_amd
+    import torch
+    rng = np.random.default_rng(77)
+    b = bw.synthetic_proteome(125, seed=31)
+    assert b.n_atoms > 262144 and np.diff(b.structure_offsets).max() > 4200
+    variants, sensitive = _id_variants(b, rng)
+    assert {"pair_inside", "pair_on_bounds_seam"} <= sensitive  # (pairs that change values: the test can tell whether ids were kept)
+    want_none = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, None, b.structure_offsets, PROBE, 100, 8, threads=0)
+    wants = {}
+    for name, ids in variants.items():
+        wants[name] = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+        assert np.array_equal(wants[name], want_none) == (name not in sensitive), name
+
+    def pin(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
+
+    passes = ("rising", "per_structure", "equal_across_structures")  # (the other columns fall somewhere inside a structure)
+    with rustsasa_amd.Context(0) as c:
+        for name, ids in variants.items():
+            bb = bw.Batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, b.residue_offsets)
+            n0 = c.ids_dropped()
+            atom, _, _ = _device_run(c, bb, want_res=False)
+            assert np.array_equal(atom, wants[name]), ("device", name)
+            assert c.ids_dropped() - n0 == (1 if name in passes else 0), ("device", name)
+            n0 = c.ids_dropped()
+            atom, res = c.calculate_sasa_batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, PROBE, 100,
+                                               residue_offsets=b.residue_offsets)
+            assert np.array_equal(atom, wants[name]), ("host, one sub-batch", name)
+            assert np.array_equal(res, po.residue_sums(wants[name], b.residue_offsets)), name
+            assert c.ids_dropped() - n0 == (1 if name in passes else 0), ("host, one sub-batch", name)
+    monkeypatch.setenv("RSASA_SUB_ATOMS", "60000")  # the pipelined path from 120 k atoms on: several sub-batches here
+    with rustsasa_amd.Context(0) as c:
+        for name, ids in variants.items():
+            for pinned in (True, False):  # (pinned ids are folded and checked by the workers, pageable ones on the device)
+                cols = [b.x, b.y, b.z, b.radius, ids]
+                if pinned:
+                    cols = [pin(a) for a in cols]
+                n0 = c.ids_dropped()
+                atom, _ = c.calculate_sasa_batch(*cols, b.structure_offsets, PROBE, 100)
+                assert np.array_equal(atom, wants[name]), ("host, pipelined", name, pinned)
+                n_drop = c.ids_dropped() - n0
+                if name in passes:
+                    assert n_drop >= 2, (name, pinned, n_drop)      # every sub-batch
+                elif name.startswith("pair"):
+                    assert 1 <= n_drop, (name, pinned, n_drop)      # every sub-batch but the pair's
+    monkeypatch.setenv("RSASA_NO_ID_CHECK", "1")    # the switch that turns the check off: same values
+    with rustsasa_amd.Context(0) as c:
+        for name in ("rising", "pair_inside"):
+            bb = bw.Batch(b.x, b.y, b.z, b.radius, variants[name], b.structure_offsets, b.residue_offsets)
+            atom, _, _ = _device_run(c, bb, want_res=False)
+            assert np.array_equal(atom, wants[name]), ("no check", name)
+        assert c.ids_dropped() == 0
+
+
 # ---- non-finite input (include/rustsasa_amd.h, "Non-finite input") ----------------------------------------------
 # The reference has no checks: NaN coordinates fall out of its arithmetic (f32::min / max skip them in the bounds,
 # `as u32` sends them to cell 0, every distance to them is NaN and fails every comparison: spatial_grid.rs:113-121,
