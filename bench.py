@@ -59,6 +59,8 @@ def parse_args(argv=None):
                    help="target wall time of the CPU baseline sample (0 disables it and the parity diff)")
     p.add_argument("--h2h-steps", type=int, default=10,
                    help="timed steps of the host-to-host leg (0 disables it)")
+    p.add_argument("--hashed-ids-steps", type=int, default=20,
+                   help="steps of the secondary measurement with unordered ids (0 = skip)")
     p.add_argument("--two-steps", type=int, default=40,
                    help="steps of the secondary one-batch-at-a-time measurement (0 = skip)")
     p.add_argument("--shard-of", type=int, default=0,
@@ -350,6 +352,14 @@ class DeviceRun:
     def step(self, counts=None):
         self.enqueue(counts)
         self.ctx.wait()
+
+
+def bw_batch_with_ids(batch, ids):
+    """The same batch with another id column."""
+    import bench_workloads as bw
+    import numpy as np
+    return bw.Batch(batch.x, batch.y, batch.z, batch.radius, np.ascontiguousarray(ids, dtype=np.uint64),
+                    batch.structure_offsets, batch.residue_offsets)
 
 
 def timed(dist, steps, fn):
@@ -665,7 +675,7 @@ def main():
     h2h = None
     if args.h2h_steps > 0:
         hres = h2h_arrays[6]
-        for _ in range(3):
+        for _ in range(max(3, 2 * args.h2h_steps)):  # (untimed: the rate of host calls settles over their first twenty or so)
             h2h_step()
         s_el = timed(dist, args.h2h_steps, h2h_step)   # one synchronous call after the other
         s_el, _, _ = aggregate(dist, red_dev, s_el, batch.n_structures, batch.n_atoms)
@@ -682,27 +692,26 @@ def main():
             h_el, h_structs, _ = aggregate(dist, red_dev, h_el, batch.n_structures, batch.n_atoms)
             h_runs.append(h_el)
         h_el = sorted(h_runs)[1]
-        stream = {"ms_per_step": round(h_el / n_stream * 1e3, 4), "value": round(h_structs * n_stream / h_el, 2),
+        stream_leg = {"ms_per_step": round(h_el / n_stream * 1e3, 4), "value": round(h_structs * n_stream / h_el, 2),
                   "steps": n_stream, "ms_per_step_runs": [round(t / n_stream * 1e3, 4) for t in h_runs],
                   "definition": "a STREAM of host batches: batch k + 1 enqueued before batch k is waited for "
                                 "(rsasa_host_batch_enqueue / _wait: two worker contexts, the calls taking turns on the link)"}
         one = {"ms_per_step": round(s_el / args.h2h_steps * 1e3, 4), "value": round(h_structs * args.h2h_steps / s_el, 2),
                "steps": args.h2h_steps,
                "definition": "rsasa_calculate_sasa_batch, each call waited for before the next"}
-        best = stream if stream["value"] >= one["value"] else one
+        best = stream_leg if stream_leg["value"] >= one["value"] else one
         h2h = {"value": best["value"], "unit": "structures/s", "ms_per_step": best["ms_per_step"], "steps": best["steps"],
-               "mode": "stream" if best is stream else "one_call_at_a_time",
+               "mode": "stream" if best is stream_leg else "one_call_at_a_time",
                "definition": "SURVEY 8d: pre-parsed SoA in pinned host memory -> per-residue values in pinned host "
-                             "memory (H2D, all kernels, D2H; a batch's sub-batches pipelined over a copy-in, a compute "
-                             "and a copy-out stream).  Both ways of calling are timed - a stream of host batches and one "
-                             "call after the other - and the faster one on this box is the value (`mode`): the link leg "
-                             "(17 bytes per atom at the rate the link holds beside running kernels) and the compute leg "
-                             "(seven sub-batches with their grid builds between the occlusion kernels) take about the "
-                             "same time, so what the stream hides - a call's fill and drain - is about what its second "
-                             "context costs (DESIGN.md 6)",
+                             "memory (H2D, all kernels, D2H).  Both ways of calling are timed - a stream of host batches "
+                             "(batch k + 1 enqueued before batch k is waited for: two worker contexts with hardware "
+                             "queues of their own, two sub-batches per call, the uploads taking the link in batch order) "
+                             "and one call after the other (a call's sub-batches pipelined over a copy-in, a compute and "
+                             "a copy-out stream) - and the faster one on this box is the value (`mode`).  The stream is "
+                             "bound by the link (DESIGN.md 6)",
                "residues_equal_hbm_run": bool(sync_equal and np.array_equal(hres, got_res)
                                               and np.array_equal(h2h_out2[0], got_res)),
-               "stream": stream, "one_call_at_a_time": one}
+               "stream": stream_leg, "one_call_at_a_time": one}
 
     # ---- secondary: one batch at a time (enqueue, wait, enqueue, ...): what a caller with a single batch sees ----
     two = None
@@ -724,6 +733,41 @@ def main():
                "occlusion_kernel_ms": round(float(np.mean(seq_occl)), 4),
                "grid_build_kernel_ms": round(float(np.mean(seq_grid)), 4),
                "definition": "the same steps one batch at a time: each step is waited for before the next is enqueued"}
+
+    # ---- secondary (rank 0, one GPU): the same batch with ids in no order, as SASAOptions::process makes them ----
+    hashed = None
+    if rank == 0 and world == 1 and not args.no_ids and args.hashed_ids_steps > 0:
+        hb = bw_batch_with_ids(batch, batch.ids * np.uint64(0x9E3779B97F4A7C15))  # (odd multiplier: a bijection, still all different)
+        hrun = DeviceRun(ctx, hb, n_points, dev, True, stream)
+        n0 = ctx.ids_dropped()
+        hrun.enqueue(k=0)
+        for i in range(1, 4):
+            hrun.enqueue(k=i % 2)
+            ctx.wait()
+        ctx.wait()
+        ctx.enable_timing(True)
+        h_occl = []
+
+        def hashed_region():
+            hrun.enqueue(k=0)
+            for i in range(1, args.hashed_ids_steps):
+                hrun.enqueue(k=i % 2)
+                ctx.wait()
+                h_occl.append(ctx.timings()["occlusion_ms"])
+            ctx.wait()
+            h_occl.append(ctx.timings()["occlusion_ms"])
+
+        hh_el = timed(dist, 1, hashed_region)
+        ctx.enable_timing(False)
+        hashed = {"value": round(batch.n_structures * args.hashed_ids_steps / hh_el, 2), "unit": "structures/s",
+                  "ms_per_step": round(hh_el / args.hashed_ids_steps * 1e3, 4), "steps": args.hashed_ids_steps,
+                  "occlusion_kernel_ms": round(float(np.mean(h_occl)), 4),
+                  "ids_dropped_batches": ctx.ids_dropped() - n0,
+                  "atoms_equal_main_run": bool(np.array_equal(hrun.outs[0][0].cpu().numpy(), got_atoms)),
+                  "definition": "the timed region's stepping with the ids replaced by 64-bit hashes (all different, in no "
+                                "order: what SASAOptions::process passes, options.rs:183): the engine's check does not "
+                                "prove these different, so the id rule stays in the kernels"}
+        del hrun
 
     # ---- secondary: weak scaling (every rank its own proteome) ----
     weak = None
@@ -855,6 +899,8 @@ def main():
             line["per_call"] = per_call
         if two:
             line["one_at_a_time"] = two
+        if hashed:
+            line["ids_as_hashes"] = hashed
         if shard_of:
             line["config"]["shard_of"] = shard_of
         if shard_parity:

@@ -148,8 +148,8 @@ def test_two_ranks_share_one_gpu():
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
-                        "--device", "0", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--h2h-steps", "0",
-                        "--two-steps", "0", "--config5-steps", "0", "--files", "0", "--per-call-seconds", "0", "--weak-steps", "0",
+                        "--device", "0", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--h2h-steps", "2",
+                        "--two-steps", "2", "--config5-steps", "0", "--files", "0", "--per-call-seconds", "0", "--weak-steps", "2",
                         "--structures", "96", "--verify-shards"], capture_output=True, text=True, env=env,
                        timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
@@ -164,6 +164,9 @@ def test_two_ranks_share_one_gpu():
     assert sum(s["structures"] for s in sp) == 96 and all(s["atoms"] >= 32768 for s in sp)  # (the matrix-core kernel's batches)
     assert all(s["atoms_equal_oracle"] and s["residues_equal_oracle"] for s in sp), sp
     assert out["config"]["outputs_of_both_workspaces_equal"] is True
+    # the secondary legs run at N > 1 too (host to host in both modes, one batch at a time, weak scaling)
+    assert out["host_to_host"]["residues_equal_hbm_run"] is True and out["weak_scaling"]["structures_per_gpu"] == 96
+    assert out["one_at_a_time"]["steps"] == 2
 
 
 def test_stream_of_host_batches_matches_the_oracle(monkeypatch):
