@@ -21,8 +21,9 @@ def main(paths, match="occlusion"):
                            r["LDS_Block_Size"], int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
             if not agg:
                 continue
-            # the last full-size dispatch
-            d = max(agg, key=lambda k: (int(meta[k][1]), int(k)))
+            # the full-size dispatch that ran longest (a batch with ids launches both instantiations of the matrix-core
+            # kernel, and the one the device's id check does not ask for returns at once)
+            d = max(agg, key=lambda k: (int(meta[k][1]), meta[k][5], int(k)))
             name, grid, vgpr, sgpr, lds, dur = meta[d]
             print(f"{f}\n  dispatch {d}: {name} grid={grid} vgpr={vgpr} sgpr={sgpr} lds={lds} dur_ns={dur}")
             waves = agg[d].get("SQ_WAVES")
