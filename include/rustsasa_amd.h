@@ -30,7 +30,8 @@ extern "C" {
 
 /* 2: rsasa_batch_wait returns the OLDEST of up to two batches in flight (version 1 had one batch in flight, so
  * "the" batch); rsasa_batch_wait_all, rsasa_context_get_simd_width, rsasa_context_bind_thread added.
- * 3: rsasa_host_batch_enqueue / _wait / _wait_all (a stream of host batches), rsasa_context_clone_settings added;
+ * 3: rsasa_host_batch_enqueue / _wait / _wait_all (a stream of host batches), rsasa_context_clone_settings,
+ *    rsasa_context_ids_dropped added;
  * nothing changed or removed. */
 #define RSASA_ABI_VERSION 3
 
