@@ -771,7 +771,10 @@ hipError_t new_stream(rsasa_context *ctx, hipStream_t *out, int level)
         uint32_t mask[16] = {};
         if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && n_cu > 0 && n_cu <= 512) {
             for (int c = 0; c < n_cu; c++) mask[c / 32] |= 1u << (c % 32);
-            return hipExtStreamCreateWithCUMask(out, (uint32_t)(n_cu + 31) / 32, mask);
+            // (such a stream is a BLOCKING one: work on the process's legacy default stream and work on it wait for each
+            // other - ordering a caller may not expect, never a wrong result)
+            if (hipExtStreamCreateWithCUMask(out, (uint32_t)(n_cu + 31) / 32, mask) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();  // (a device that does not take the mask: a pooled queue then)
         }
     }
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
