@@ -765,8 +765,9 @@ def main():
                   "ids_dropped_batches": ctx.ids_dropped() - n0,
                   "atoms_equal_main_run": bool(np.array_equal(hrun.outs[0][0].cpu().numpy(), got_atoms)),
                   "definition": "the timed region's stepping with the ids replaced by 64-bit hashes (all different, in no "
-                                "order: what SASAOptions::process passes, options.rs:183): the engine's check does not "
-                                "prove these different, so the id rule stays in the kernels"}
+                                "order: what SASAOptions::process passes, options.rs:183): one comparison per atom does not "
+                                "prove these different; a hash table per structure in LDS does (k_ids_distinct, 0.08 ms per "
+                                "batch), and the batches run without ids as well"}
         del hrun
 
     # ---- secondary: weak scaling (every rank its own proteome) ----
@@ -864,11 +865,12 @@ def main():
                        "grid_cells_rank0": cells[0],
                        "atoms_per_s": round(total_atoms * args.steps / elapsed, 1),
                        "ids": not args.no_ids,
-                       "ids_note": "one 64-bit id per atom is passed, as the reference's Atom carries one; they increase "
-                                   "within every structure (indices, as the reference's callers set them), the engine's "
-                                   "check finds that (k_bounds on the device, the coding threads on the host) and runs "
-                                   "the batches without them - same values (parity below is against the oracle WITH the "
-                                   "ids); rsasa_context_ids_dropped counts the (sub-)batches",
+                       "ids_note": "one 64-bit id per atom is passed, as the reference's Atom carries one; the engine checks "
+                                   "whether the ids of every structure are all different (these rise within every "
+                                   "structure, like serials and indices: one comparison per atom in k_bounds or in the "
+                                   "host's coding threads; ids in no order: `ids_as_hashes`) and runs such batches "
+                                   "without them - same values (parity below is against the oracle WITH the ids); "
+                                   "rsasa_context_ids_dropped counts the (sub-)batches",
                        "ids_dropped_batches": ctx.ids_dropped(),
                        "numa_node": numa["numa_node"], "cpus": numa["cpus"], "cpu_list": numa["cpu_list"],
                        "gpu_pci": numa["gpu_pci"],

@@ -257,13 +257,15 @@ int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out);
 
 /* Ids only matter where two atoms of one structure share one (a neighbour with
  * the atom's own id is skipped: reference src/lib.rs:127).  Large batches are
- * checked - by the device for device-resident ids, by the host's coding
- * threads for host batches - and when the ids of every structure increase
- * strictly (atom serials, indices: all different) the batch, or the sub-batch
- * of a pipelined host call, runs as one WITHOUT ids: the same values, no id
- * traffic, the id-less kernels (4 % faster).  This statistic counts the
- * (sub-)batches of the context, its stream of host batches included, that
- * ran so. */
+ * checked, and when the ids of every structure are all different the batch,
+ * or the sub-batch of a pipelined host call, runs as one WITHOUT ids: the
+ * same values, no id traffic, the id-less kernels (4 % faster).  Ids that
+ * increase strictly within every structure (atom serials, indices) are found
+ * by one comparison per atom, on the device or by the host's coding threads;
+ * 64-bit ids in no order (hashes) that are on the device go through a hash
+ * table per structure (up to 27 648 atoms per structure).  This statistic
+ * counts the (sub-)batches of the context, its stream of host batches
+ * included, that ran so. */
 int rsasa_context_ids_dropped(rsasa_context_t *ctx, uint64_t *out_batches);
 
 /* ---- utilities --------------------------------------------------------- */

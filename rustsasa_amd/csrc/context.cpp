@@ -806,27 +806,35 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
 
     // bounds segments: <= kSegmentAtoms atoms of one structure each
     size_t n_seg = 0;
+    // (behind the segments, in the same upload: the structures whose ids k_ids_distinct's large table takes)
+    size_t n_large = 0;
+    bool ids_too_big = false;
     for (size_t s = 0; s < S; s++) {
         const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
         n_seg += (e - b + kSegmentAtoms - 1) / kSegmentAtoms;
+        n_large += e - b > kIdAtomsSmall && e - b <= kIdAtomsLarge;
+        ids_too_big |= e - b > kIdAtomsLarge;
     }
-    if (n_seg > hs.h_segments_cap) {
+    const size_t n_seg_all = n_seg + (n_large + 3) / 4;  // (four structure numbers per segment-sized entry)
+    if (n_seg_all > hs.h_segments_cap) {
         if (hs.h_segments) {
             RS_HIP(ctx, hipStreamSynchronize(pd.stream));
             RS_HIP(ctx, hipHostFree(hs.h_segments));
             hs.h_segments = nullptr;
             hs.h_segments_cap = 0;
         }
-        const size_t cap = n_seg + n_seg / 2 + 64;
+        const size_t cap = n_seg_all + n_seg_all / 2 + 64;
         RS_HIP(ctx, hipHostMalloc((void **)&hs.h_segments, cap * sizeof(Segment), hipHostMallocDefault));
         hs.h_segments_cap = cap;
     }
     bool has_tail = false;  // some structure is too large for the LDS binning: the batch-wide kernels run too
     {
-        size_t k = 0;
+        size_t k = 0, kl = 0;
+        uint32_t *large = reinterpret_cast<uint32_t *>(hs.h_segments + n_seg);
         for (size_t s = 0; s < S; s++) {
             const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
             has_tail |= e - b >= kLdsMaxAtoms;
+            if (e - b > kIdAtomsSmall && e - b <= kIdAtomsLarge) large[kl++] = (uint32_t)s;
             for (uint32_t a = b; a < e; a += kSegmentAtoms)
                 hs.h_segments[k++] = Segment{(uint32_t)s, a, std::min(e, a + kSegmentAtoms), a != b ? 1u : 0u};
         }
@@ -837,7 +845,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     ctx->cell_capacity = std::min<uint64_t>(ctx->cell_capacity, 0xFFFFFFF0ull);
 
     const bool has_id = bt.id != nullptr;  // (with pd.id32 set, bt.id is the general kernel's device-accessible copy)
-    if ((rc = reserve(ctx, W.segments, std::max<size_t>(n_seg, 1) * sizeof(Segment)))) return rc;
+    if ((rc = reserve(ctx, W.segments, std::max<size_t>(n_seg_all, 1) * sizeof(Segment)))) return rc;
     if ((rc = reserve(ctx, W.acc, std::max<size_t>(S, 1) * sizeof(StructAcc)))) return rc;
     if ((rc = reserve(ctx, W.grids, std::max<size_t>(S, 1) * sizeof(StructGrid)))) return rc;
     if ((rc = reserve(ctx, W.grid_sums, (std::max<size_t>(S, 1) + 255) / 256 * 32))) return rc;
@@ -863,8 +871,8 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, W.status, sizeof(BatchStatus)))) return rc;
     if (!bt.out_atom_sasa && (rc = reserve(ctx, W.atom_sasa, std::max<size_t>(N, 1) * 4))) return rc;
 
-    if (n_seg)
-        RS_HIP(ctx, hipMemcpyAsync(W.segments.p, hs.h_segments, n_seg * sizeof(Segment),
+    if (n_seg_all)
+        RS_HIP(ctx, hipMemcpyAsync(W.segments.p, hs.h_segments, n_seg_all * sizeof(Segment),
                                    hipMemcpyHostToDevice, st));
 
     BatchView v{};
@@ -874,6 +882,9 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     // unless the host has looked already (pd.ids_needed_known: the host paths check before they upload)
     v.ids_check = (has_id && !pd.id32 && !pd.ids_needed_known && !keep_ids && !tuning_env("RSASA_NO_ID_CHECK")) ? 1u : 0u;
     hs.ids_check = v.ids_check != 0u;
+    v.large_sids = reinterpret_cast<const uint32_t *>((const Segment *)W.segments.p + n_seg);
+    v.n_large = (uint32_t)n_large;
+    v.ids_too_big = ids_too_big ? 1u : 0u;
     v.radius8 = pd.radius8;
     v.radius_table = pd.radius_table;
     v.residue_offsets = bt.residue_offsets;

@@ -65,9 +65,10 @@ struct BatchStatus {
     uint32_t tail_atom_base;  // their first position in the cell-sorted arrays (= atoms of the LDS-binned structures)
     uint32_t n_windows;       // entries of BatchView::windows (work list of k_sort_window)
     uint64_t grid_cells;      // cells of all grids (statistic)
-    uint32_t ids_needed;      // BatchView::ids_check: 0 = the ids of every structure increase strictly, so they are all
-                              // different and "another atom with my id" never happens - the batch runs as one without ids
-    uint32_t pad_;
+    uint32_t ids_needed;      // BatchView::ids_check: 0 = the ids of every structure are all different, so "another atom
+                              // with my id" never happens - the batch runs as one without ids
+    uint32_t ids_unordered;   // the same: some id does not rise above its predecessor's (k_bounds); k_ids_distinct then looks
+                              // for equal ids structure by structure
 };
 static_assert(sizeof(BatchStatus) == 56, "BatchStatus layout");
 
@@ -111,10 +112,14 @@ struct BatchView {
     float probe;
     // Ids only matter where two atoms of a structure share one (lib.rs:127: a neighbour with the atom's own id is
     // skipped).  1: k_bounds also checks that the ids of every structure increase strictly (what atom serials and indices
-    // do), and while BatchStatus::ids_needed stays 0 every later kernel treats the batch as one WITHOUT ids - no id loads,
-    // no sorted copies, the occlusion kernel's id-less instantiation (4 % faster) - with identical results.  Set for
-    // batches with 64-bit device ids that the matrix-core kernel takes.
+    // do); if they do not (hashes), k_ids_distinct puts every structure's ids through a hash table in LDS; and while
+    // BatchStatus::ids_needed stays 0 every later kernel treats the batch as one WITHOUT ids - no id loads, no sorted
+    // copies, the occlusion kernel's id-less instantiation (4 % faster) - with identical results.  Set for batches with
+    // 64-bit device ids that the matrix-core kernel takes.
     uint32_t ids_check;
+    const uint32_t *large_sids;    // k_ids_distinct: the structures of more than kIdAtomsSmall (and at most kIdAtomsLarge) atoms
+    uint32_t n_large;
+    uint32_t ids_too_big;          // some structure has more than kIdAtomsLarge atoms: ids in no order stay in play
     // workspace
     const Segment *segments;
     StructAcc *acc;
@@ -201,6 +206,9 @@ constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
 #define RSASA_SORT_THREADS 1024
 #endif
 constexpr uint32_t kWindowCells = RSASA_WINDOW_CELLS;  // cells one k_sort_window workgroup bins (16-bit counters, 72 KiB: two per CU)
+// k_ids_distinct (BatchView::ids_check): a table of 8 192 slots in LDS for structures of up to 4 096 atoms (32 KB: several
+// workgroups per CU), one of 36 864 for up to 27 648 (144 KB, one workgroup per such structure)
+constexpr uint32_t kIdSlotsSmall = 8192, kIdAtomsSmall = 4096, kIdSlotsLarge = 36864, kIdAtomsLarge = 27648;
 constexpr uint32_t kLdsMaxAtoms = 65536;  // structures with fewer atoms are binned in LDS (16-bit positions)
 
 // 16-bit entries a structure of n_cells cells takes in the cell array: its cells, the end marker,

@@ -35,7 +35,8 @@ __global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *s
         status->tail_atom_base = 0;
         status->n_windows = 0;
         status->grid_cells = 0;
-        status->ids_needed = ids_needed;  // (0 with BatchView::ids_check: k_bounds raises it)
+        status->ids_needed = ids_needed;  // (0 with BatchView::ids_check: k_ids_distinct raises it)
+        status->ids_unordered = 0;        // (k_bounds raises it)
     }
     if (s >= n_structures) return;
     const int pinf = f2ord(__int_as_float(0x7F800000)), ninf = f2ord(__int_as_float(0xFF800000));
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         bool falls = false;
         for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x)
             if (i > seg.begin || seg.continues) falls |= b.id[i] <= b.id[i - 1u];
-        if (falls) b.status->ids_needed = 1u;
+        if (falls) b.status->ids_unordered = 1u;
     }
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
         float x = b.x[i], y = b.y[i], z = b.z[i], r = load_radius(b.radius, b.radius8, b.radius_table, i);
@@ -103,6 +104,42 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         atomicMin(&b.acc[seg.sid].first_atom, seg.begin);
     }
     if (ballot64(odd_r) != 0ull && lane_id() == 0) atomicOr(&b.acc[seg.sid].odd_radii, 1);
+}
+
+// BatchView::ids_check, second step - only when k_bounds found ids that do not rise (hashes: what SASAOptions::process
+// passes, options.rs:183): are the ids of every structure all different?  One workgroup per structure puts its ids into
+// an open-addressing table in LDS (the entry is the atom's number; an occupied slot is decided on the full 64-bit ids, so
+// the answer is exact whatever the hash does); the first equal pair raises BatchStatus::ids_needed.  Two launches share
+// the structures by size (device_types.h kIdSlotsSmall / kIdSlotsLarge): one workgroup per structure with the small
+// table - larger structures are not its business -, and one per entry of the host's list of larger structures with the
+// large one (a workgroup that only finds out that it has nothing to do would still wait for 144 KB of LDS).
+template <uint32_t SLOTS, uint32_t THREADS, bool LARGE>
+__global__ __launch_bounds__(THREADS) void k_ids_distinct(BatchView b)
+{
+    if (b.status->ids_unordered == 0u || b.status->ids_needed != 0u) return;
+    if (b.ids_too_big) {
+        if (blockIdx.x == 0u && threadIdx.x == 0u) b.status->ids_needed = 1u;
+        return;
+    }
+    const uint32_t s = LARGE ? b.large_sids[blockIdx.x] : blockIdx.x;
+    const uint32_t n = b.acc[s].n_atoms, a0 = b.acc[s].first_atom;
+    if (n < 2u || (!LARGE && n > kIdAtomsSmall)) return;
+    __shared__ uint32_t s_tab[SLOTS];
+    for (uint32_t k = threadIdx.x; k < SLOTS; k += THREADS) s_tab[k] = 0u;
+    __syncthreads();
+    const uint64_t *__restrict__ id = b.id + a0;
+    bool equal = false;
+    for (uint32_t i = threadIdx.x; i < n && !equal; i += THREADS) {
+        const uint64_t mine = id[i];
+        uint32_t h = (uint32_t)(((uint64_t)(fold_id(mine) * 0x9E3779B1u) * SLOTS) >> 32);
+        for (;;) {
+            const uint32_t there = atomicCAS(&s_tab[h], 0u, i + 1u);
+            if (there == 0u) break;
+            if (id[there - 1u] == mine) { equal = true; break; }
+            h = h + 1u == SLOTS ? 0u : h + 1u;
+        }
+    }
+    if (equal) b.status->ids_needed = 1u;
 }
 
 // SpatialGrid::new parameters (spatial_grid.rs:35-44 with cell_size from lib.rs:76).
@@ -745,6 +782,12 @@ void launch_grid_prepare(const BatchView &b, hipStream_t stream)
                        b.acc, b.n_structures, b.status, b.ids_check ? 0u : 1u);
     if (b.n_segments)
         hipLaunchKernelGGL(k_bounds, dim3(b.n_segments), dim3(256), 0, stream, b);
+    if (b.ids_check && b.n_structures) {
+        // (both return at once unless k_bounds found ids that do not rise)
+        hipLaunchKernelGGL((k_ids_distinct<kIdSlotsSmall, 256u, false>), dim3(b.n_structures), dim3(256), 0, stream, b);
+        if (b.n_large && !b.ids_too_big)
+            hipLaunchKernelGGL((k_ids_distinct<kIdSlotsLarge, 1024u, true>), dim3(b.n_large), dim3(1024), 0, stream, b);
+    }
     const uint32_t n_parts = cdiv(b.n_structures > 0 ? b.n_structures : 1, 256);
     hipLaunchKernelGGL(k_grid_params, dim3(n_parts), dim3(256), 0, stream, b);
     if (n_parts <= 256) hipLaunchKernelGGL(k_grid_scan<1>, dim3(1), dim3(64), 0, stream, b, n_parts);

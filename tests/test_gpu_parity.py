@@ -1050,7 +1050,8 @@ def _id_variants(b, rng):
     sizes = np.diff(so)
     rising = np.arange(n, dtype=np.uint64) * 3 + 10
     per_structure = np.concatenate([np.arange(m, dtype=np.uint64) for m in sizes])  # serials start over: still all different
-    out = {"rising": rising, "per_structure": per_structure, "falling": rising[::-1].copy()}
+    hashed = rising * np.uint64(0x9E3779B97F4A7C15)  # (an odd multiplier: a bijection - all different, in no order)
+    out = {"rising": rising, "per_structure": per_structure, "falling": rising[::-1].copy(), "hashed": hashed}
     sensitive = set()
     base_of = {}
 
@@ -1091,15 +1092,24 @@ def _id_variants(b, rng):
     eq_across = rising.copy()                        # the last atom of a structure and the first of the next: not a pair
     eq_across[so[2]] = eq_across[so[2] - 1]
     out["equal_across_structures"] = eq_across
+    for name in [k for k in out if k.startswith("pair")]:  # the same pairs among ids in no order
+        ids = out[name]
+        out["hashed_" + name] = ids * np.uint64(0x9E3779B97F4A7C15)
+        if name in sensitive:
+            sensitive.add("hashed_" + name)
+    hashed_eq = hashed.copy()
+    hashed_eq[so[5]] = hashed_eq[so[3] + 1]          # equal ids in DIFFERENT structures: not a pair either
+    out["hashed_equal_in_two_structures"] = hashed_eq
     return out, sensitive
 
 
 def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch):
     """Ids only matter where two atoms of one structure share one (lib.rs:127).  The engine checks whether the ids of
-    every structure increase strictly and runs such a batch as one without ids; a single repeated id anywhere must keep
-    the ids in play.  Device-resident batches (checked by k_bounds), one large host sub-batch (checked by the coding
-    workers while the coordinates upload) and pipelined host batches (checked per sub-batch while the ids are folded),
-    every atom against the oracle."""
+    every structure are all different - they rise (one comparison per atom: k_bounds, or the host's coding workers), or,
+    for 64-bit ids on the device, a hash table per structure says so (k_ids_distinct) - and runs such a batch as one
+    without ids; a single repeated id anywhere must keep the ids in play.  Device-resident batches, one large host
+    sub-batch and pipelined host batches with pinned (folded) and pageable ids, every atom against the oracle and the
+    drop counter against what should have been dropped."""
     import rustsasa_amd
     import torch
     rng = np.random.default_rng(77)
@@ -1116,20 +1126,21 @@ def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch
     def pin(a):
         return torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
 
-    passes = ("rising", "per_structure", "equal_across_structures")  # (the other columns fall somewhere inside a structure)
+    rises = ("rising", "per_structure", "equal_across_structures")      # found by one comparison per atom, host or device
+    distinct = rises + ("falling", "hashed", "hashed_equal_in_two_structures")  # the others need the device's hash tables
     with rustsasa_amd.Context(0) as c:
         for name, ids in variants.items():
             bb = bw.Batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, b.residue_offsets)
             n0 = c.ids_dropped()
             atom, _, _ = _device_run(c, bb, want_res=False)
             assert np.array_equal(atom, wants[name]), ("device", name)
-            assert c.ids_dropped() - n0 == (1 if name in passes else 0), ("device", name)
+            assert c.ids_dropped() - n0 == (1 if name in distinct else 0), ("device", name)
             n0 = c.ids_dropped()
             atom, res = c.calculate_sasa_batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, PROBE, 100,
                                                residue_offsets=b.residue_offsets)
             assert np.array_equal(atom, wants[name]), ("host, one sub-batch", name)
             assert np.array_equal(res, po.residue_sums(wants[name], b.residue_offsets)), name
-            assert c.ids_dropped() - n0 == (1 if name in passes else 0), ("host, one sub-batch", name)
+            assert c.ids_dropped() - n0 == (1 if name in distinct else 0), ("host, one sub-batch", name)
     monkeypatch.setenv("RSASA_SUB_ATOMS", "60000")  # the pipelined path from 120 k atoms on: several sub-batches here
     with rustsasa_amd.Context(0) as c:
         for name, ids in variants.items():
@@ -1141,10 +1152,21 @@ def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch
                 atom, _ = c.calculate_sasa_batch(*cols, b.structure_offsets, PROBE, 100)
                 assert np.array_equal(atom, wants[name]), ("host, pipelined", name, pinned)
                 n_drop = c.ids_dropped() - n0
-                if name in passes:
+                if name in rises or (name in distinct and not pinned):
                     assert n_drop >= 2, (name, pinned, n_drop)      # every sub-batch
-                elif name.startswith("pair"):
+                elif name in distinct:
+                    assert n_drop == 0, (name, pinned, n_drop)      # (pinned ids in no order travel as folds: nothing to prove them different with)
+                elif name.startswith("pair") or not pinned:
                     assert 1 <= n_drop, (name, pinned, n_drop)      # every sub-batch but the pair's
+    # a structure too large for the hash table (more than 27 648 atoms) keeps ids in no order in play; rising ones still go
+    big = bw.synthetic_uniform(40_000, seed=3)
+    with rustsasa_amd.Context(0) as c:
+        for ids, dropped in ((big.ids * np.uint64(0x9E3779B97F4A7C15), 0), (big.ids, 1)):
+            bb = bw.Batch(big.x, big.y, big.z, big.radius, ids, big.structure_offsets, big.residue_offsets)
+            atom, _, _ = _device_run(c, bb, want_res=False)
+            assert np.array_equal(atom, po.calculate_sasa_batch(big.x, big.y, big.z, big.radius, ids, big.structure_offsets,
+                                                                PROBE, 100, 8, threads=0))
+            assert c.ids_dropped() == dropped
     monkeypatch.setenv("RSASA_NO_ID_CHECK", "1")    # the switch that turns the check off: same values
     with rustsasa_amd.Context(0) as c:
         for name in ("rising", "pair_inside"):
