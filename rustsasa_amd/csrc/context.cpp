@@ -492,6 +492,7 @@ struct rsasa_context {
         bool ids_check = false;         // the batch that last used the slot ran with BatchView::ids_check
     } slot[kSlots];
     std::atomic<uint64_t> ids_dropped{0};         // batches / sub-batches that ran without their ids (rsasa_context_ids_dropped)
+    bool ids_drop_hint = true;                    // what the last checked batch did (OcclusionChain::expect_ids_dropped)
     hipEvent_t ev_done[kSlots] = {};              // all work of the sub-batch in slot k has been executed
     uint64_t cell_capacity = 0;
 
@@ -956,11 +957,16 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
             RS_HIP(ctx, hipEventRecord(ctx->ev_grid[pd.ws], gst));
             RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_grid[pd.ws], 0));
         }
-        if (chain) RS_HIP(ctx, hipStreamWaitEvent(st, other.ev_occ, 0));
-        if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[2], st));
-        launch_occlusion(v, lat, ctx->tuning, kOccAll, st);
+        // (the wait for the other batch's occlusion kernel, the timing event and this batch's "occlusion kernel has ended"
+        // event sit around the launch that does the work: OcclusionChain)
+        OcclusionChain oc;
+        oc.wait = chain ? other.ev_occ : nullptr;
+        oc.start = ctx->timing ? W.ev[2] : nullptr;
+        oc.done = W.ev_occ;
+        oc.expect_ids_dropped = ctx->ids_drop_hint;
+        launch_occlusion(v, lat, ctx->tuning, kOccAll, st, &oc);
     }
-    RS_HIP(ctx, hipEventRecord(W.ev_occ, st));
+    if (overlap) RS_HIP(ctx, hipEventRecord(W.ev_occ, st));
     W.occ_recorded = true;
     if (ctx->timing) RS_HIP(ctx, hipEventRecord(W.ev[3], st));
     launch_residue_sums(v, st);
@@ -995,7 +1001,10 @@ int wait_one(rsasa_context *ctx, Pending &pd)
         }
         if (!stt.overflow) {
             ctx->tuning.deferred_hint = stt.deferred;  // (sizes the next batch's launch over its deferred list)
-            if (ctx->slot[pd.ws].ids_check && !stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+            if (ctx->slot[pd.ws].ids_check) {
+                ctx->ids_drop_hint = !stt.ids_needed;
+                if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+            }
             if (ctx->timing) {
                 float g = 0, o = 0, a = 0, t = 0;
                 (void)hipEventElapsedTime(&g, W.ev[0], W.ev[1]);
@@ -2050,7 +2059,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                 err = fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius + max radius must be a positive finite number");
             if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
             else ctx->tuning.deferred_hint = stt.deferred;
-            if (!stt.overflow && ctx->slot[k].ids_check && !stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+            if (!stt.overflow && ctx->slot[k].ids_check) {
+                ctx->ids_drop_hint = !stt.ids_needed;
+                if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+            }
         };
         bool used[kSlots] = {};
         if (fold_ids || code_radii) {

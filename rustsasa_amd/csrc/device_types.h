@@ -185,8 +185,19 @@ enum OcclusionPart : uint32_t {
     kOccHead = 1,  // positions below BatchStatus::tail_atom_base (LDS-binned structures); may launch nothing
     kOccRest = 2,  // whatever kOccHead did not launch, plus the deferred atoms
 };
+// Two batches in flight: a batch's occlusion kernel starts when the other batch's has ended, and "has ended" is an event
+// recorded right behind THAT kernel - not behind the launches that follow it (the instantiation the id check does not ask
+// for, which returns at once, and the general kernel over the deferred list: 25 us that the next occlusion kernel then
+// does not wait for).  launch_occlusion waits for `wait` in front of the launch that does the work, records `start` (timing,
+// nullable) there and `done` behind it.  With BatchView::ids_check the host does not know which instantiation will work:
+// `expect_ids_dropped` (what the context's last batch did) puts the other one FIRST, in front of the wait, where it runs
+// beside the neighbour's kernel for nothing; a wrong guess only loses the ordering for that batch.
+struct OcclusionChain {
+    hipEvent_t wait = nullptr, start = nullptr, done = nullptr;
+    bool expect_ids_dropped = true;
+};
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
-                      OcclusionPart part, hipStream_t stream);
+                      OcclusionPart part, hipStream_t stream, const OcclusionChain *chain = nullptr);
 // Whether launch_occlusion gives a batch of n_atoms atoms to the matrix-core kernel.
 bool occlusion_uses_mx(const OcclusionTuning &tune, const Lattice &lat, uint32_t n_atoms);
 // The general kernel over the atoms the straight-line kernel deferred (see BatchView::defer_flag).

@@ -97,8 +97,28 @@ uint32_t device_cus()
 }
 
 // NW waves per workgroup, each with up to atoms_per_wave atoms
+// OcclusionChain: in front of / behind the launch that does a batch's occlusion work
+void chain_begin(const OcclusionChain *chain, hipStream_t stream)
+{
+    if (!chain) return;
+    if (chain->wait) (void)hipStreamWaitEvent(stream, chain->wait, 0);  // (a failure shows as the launch's)
+    if (chain->start) (void)hipEventRecord(chain->start, stream);
+}
+void chain_end(const OcclusionChain *chain, hipStream_t stream)
+{
+    if (chain && chain->done) (void)hipEventRecord(chain->done, stream);
+}
+
+template <int NT, bool HAS_ID, bool MULTI, int NW>
+void launch_mx1(bool rem, uint32_t n_blocks, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
+{
+    if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, HAS_ID, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+    else hipLaunchKernelGGL((k_occlusion_mx<NT, HAS_ID, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+}
+
 template <int NT, bool MULTI, int NW>
-void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3)
+void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipStream_t stream, const OccArgs3 &a3,
+               const OcclusionChain *chain)
 {
     // persistent waves (occlusion_mx.inc): as many workgroups as the GPU holds at once - 28 waves per CU at 72
     // registers, 24 at 80 (NW >= 8) - or fewer when the batch has fewer blocks of atoms_per_wave atoms than that
@@ -108,14 +128,19 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
     if (has_id && a3.ids_check) {
         // BatchView::ids_check: whether the ids matter is known on the device only - both instantiations are launched, the
         // one that BatchStatus::ids_needed does not ask for returns at once (its workgroups touch nothing, the claim
-        // counters included)
-        if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
-        else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+        // counters included).  The one the host expects to return goes first, in front of the chain's wait.
+        const bool dropped = !chain || chain->expect_ids_dropped;
+        if (dropped) launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        else launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        chain_begin(chain, stream);
+        if (dropped) launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        else launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+    } else {
+        chain_begin(chain, stream);
+        if (has_id) launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        else launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
     }
-    if (has_id && rem) hipLaunchKernelGGL((k_occlusion_mx<NT, true, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
-    else if (has_id) hipLaunchKernelGGL((k_occlusion_mx<NT, true, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
-    else if (rem) hipLaunchKernelGGL((k_occlusion_mx<NT, false, true, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
-    else hipLaunchKernelGGL((k_occlusion_mx<NT, false, false, MULTI, NW>), dim3(n_blocks), dim3(64 * NW), lds_bytes, stream, a3);
+    chain_end(chain, stream);
 }
 
 // Waves per workgroup of k_occlusion_mx with at most 128 points.  4: the waves share an LDS copy of the point tables.
@@ -157,8 +182,16 @@ void launch_fast(bool has_id, bool rem, bool half1, uint32_t n_blocks, hipStream
 }  // namespace
 
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
-                      OcclusionPart part, hipStream_t stream)
+                      OcclusionPart part, hipStream_t stream, const OcclusionChain *chain)
 {
+    // (the chain's events are recorded on every path: only the matrix-core kernel's launch places them itself)
+    struct ChainGuard {
+        const OcclusionChain *chain;
+        hipStream_t stream;
+        bool begun = false, ended = false;
+        void begin() { if (!begun) { chain_begin(chain, stream); begun = true; } }
+        ~ChainGuard() { begin(); if (!ended) chain_end(chain, stream); }
+    } guard{chain, stream};
     if (!b.n_atoms) return;
     OccArgs a{b, lat, 0, 1, tune.debug_stop};
     const uint32_t n_chunks = (lat.n_points + kWave - 1) / kWave;
@@ -170,6 +203,7 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
     const bool fast = tune.kernel_version >= 4 && tune.debug_stop == 0 && (n_chunks <= 2 || mx) &&
                       lat.n_points - lat.n_fused <= kFastMaxRem;
     if (!fast && part == kOccHead) return;  // only the fast kernel takes a partial range
+    if (!(fast && mx)) guard.begin();  // (launch_mx places the chain's events around its working launch)
     if (tune.kernel_version == 0) {
         // reference kernel: all candidates against all points, one atom per wave
         a.n_blocks = cdiv(b.n_atoms, 4);
@@ -218,9 +252,9 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // (-DMX_NW=1: single-wave workgroups, the tables read from Lattice::mx_tab, no dynamic LDS)
             constexpr int kNW = MX_NW;
             constexpr uint32_t kTabs = kNW == 1 ? 0u : 1u;
-            if (lat.n_points <= 96u) launch_mx<6, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 96u + 256u), stream, a3);
-            else if (lat.n_points <= 112u) launch_mx<7, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 112u + 256u), stream, a3);
-            else if (lat.n_points <= 128u) launch_mx<8, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 128u + 256u), stream, a3);
+            if (lat.n_points <= 96u) launch_mx<6, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 96u + 256u), stream, a3, chain);
+            else if (lat.n_points <= 112u) launch_mx<7, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 112u + 256u), stream, a3, chain);
+            else if (lat.n_points <= 128u) launch_mx<8, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 128u + 256u), stream, a3, chain);
             else {
                 // More points: whole tiles of 16 points in the two tables, the patch table behind them (16 bytes per tile,
                 // whole blocks of 64, and a zero entry).  The tables are per workgroup, the lists per wave (3.4 KB): pick
@@ -239,10 +273,11 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
 #ifdef MX_FORCE_NW  // experiments only
                 best_nw = MX_FORCE_NW;
 #endif
-                if (best_nw == 4u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, dyn, stream, a3);
-                else if (best_nw == 8u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, dyn, stream, a3);
-                else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, dyn, stream, a3);
+                if (best_nw == 4u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, dyn, stream, a3, chain);
+                else if (best_nw == 8u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, dyn, stream, a3, chain);
+                else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, dyn, stream, a3, chain);
             }
+            guard.begun = guard.ended = true;  // (done by launch_mx)
         } else {
             launch_fast(b.id != nullptr, rem, half1, a.n_blocks, stream, a3);
         }
