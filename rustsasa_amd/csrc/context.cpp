@@ -493,6 +493,7 @@ struct rsasa_context {
     } slot[kSlots];
     std::atomic<uint64_t> ids_dropped{0};         // batches / sub-batches that ran without their ids (rsasa_context_ids_dropped)
     bool ids_drop_hint = true;                    // what the last checked batch did (OcclusionChain::expect_ids_dropped)
+    bool ids_unordered_hint = false;              // its ids were in no order: the next batch brings the id tables (BatchView::ids_tables)
     hipEvent_t ev_done[kSlots] = {};              // all work of the sub-batch in slot k has been executed
     uint64_t cell_capacity = 0;
 
@@ -886,6 +887,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.large_sids = reinterpret_cast<const uint32_t *>((const Segment *)W.segments.p + n_seg);
     v.n_large = (uint32_t)n_large;
     v.ids_too_big = ids_too_big ? 1u : 0u;
+    v.ids_tables = ctx->ids_unordered_hint ? 1u : 0u;
     v.radius8 = pd.radius8;
     v.radius_table = pd.radius_table;
     v.residue_offsets = bt.residue_offsets;
@@ -1003,6 +1005,7 @@ int wait_one(rsasa_context *ctx, Pending &pd)
             ctx->tuning.deferred_hint = stt.deferred;  // (sizes the next batch's launch over its deferred list)
             if (ctx->slot[pd.ws].ids_check) {
                 ctx->ids_drop_hint = !stt.ids_needed;
+                ctx->ids_unordered_hint = stt.ids_unordered != 0;
                 if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             }
             if (ctx->timing) {
@@ -2061,6 +2064,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             else ctx->tuning.deferred_hint = stt.deferred;
             if (!stt.overflow && ctx->slot[k].ids_check) {
                 ctx->ids_drop_hint = !stt.ids_needed;
+                ctx->ids_unordered_hint = stt.ids_unordered != 0;
                 if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             }
         };

@@ -120,6 +120,9 @@ struct BatchView {
     const uint32_t *large_sids;    // k_ids_distinct: the structures of more than kIdAtomsSmall (and at most kIdAtomsLarge) atoms
     uint32_t n_large;
     uint32_t ids_too_big;          // some structure has more than kIdAtomsLarge atoms: ids in no order stay in play
+    uint32_t ids_tables;           // the k_ids_distinct launches are part of this batch (the context's last checked batch had
+                                   // ids in no order); 0: they are not - their workgroups wait for LDS even to return -, and
+                                   // ids that do not rise simply stay in play for this batch
     // workspace
     const Segment *segments;
     StructAcc *acc;

@@ -65,11 +65,10 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
         bool falls = false;
         for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x)
             if (i > seg.begin || seg.continues) falls |= b.id[i] <= b.id[i - 1u];
-#ifndef RSASA_NO_ID_TABLES
-        if (falls) b.status->ids_unordered = 1u;
-#else
-        if (falls) b.status->ids_needed = 1u;
-#endif
+        if (falls) {
+            b.status->ids_unordered = 1u;
+            if (!b.ids_tables) b.status->ids_needed = 1u;  // (nobody will look closer this time)
+        }
     }
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
         float x = b.x[i], y = b.y[i], z = b.z[i], r = load_radius(b.radius, b.radius8, b.radius_table, i);
@@ -791,17 +790,15 @@ void launch_grid_prepare(const BatchView &b, hipStream_t stream)
     if (n_parts <= 256) hipLaunchKernelGGL(k_grid_scan<1>, dim3(1), dim3(64), 0, stream, b, n_parts);
     else hipLaunchKernelGGL(k_grid_scan<16>, dim3(1), dim3(1024), 0, stream, b, n_parts);
     hipLaunchKernelGGL(k_grid_bases, dim3(n_parts), dim3(256), 0, stream, b);
-#ifndef RSASA_NO_ID_TABLES  // (measurement builds: ids in no order then keep the id rule, k_bounds' flag standing for "needed")
-    if (b.ids_check && b.n_structures) {
-        // Both return at once unless k_bounds found ids that do not rise.  Last of the small kernels: their workgroups ask
-        // for 32 / 144 KB of LDS even to return, which they only get in the tail of the neighbouring batch's occlusion kernel -
-        // where the binning that follows waits anyway; in front of the grid kernels they held those up as well (+0.04 ms per
-        // step).
+    if (b.ids_check && b.ids_tables && b.n_structures) {
+        // Both return at once unless k_bounds found ids that do not rise - but their workgroups ask for 32 / 144 KB of LDS
+        // even to return, which they only get in the tail of the neighbouring batch's occlusion kernel: they are only
+        // launched when the context's last batch had such ids (BatchView::ids_tables), and last of the small kernels, where
+        // the binning that follows waits for LDS anyway (in front of the grid kernels they held those up as well).
         hipLaunchKernelGGL((k_ids_distinct<kIdSlotsSmall, 256u, false>), dim3(b.n_structures), dim3(256), 0, stream, b);
         if (b.n_large && !b.ids_too_big)
             hipLaunchKernelGGL((k_ids_distinct<kIdSlotsLarge, 1024u, true>), dim3(b.n_large), dim3(1024), 0, stream, b);
     }
-#endif
 }
 
 // Binning of the structures with fewer than 65536 atoms: one workgroup per window of cells.  The
