@@ -52,6 +52,10 @@ with rustsasa_amd.Context(0) as ctx:
         ids = np.arange(len(xyz), dtype=np.uint64)
         if rng.random() < 0.3 and len(ids) > 4:  # some duplicated ids
             k = rng.integers(len(ids), size=max(1, len(ids) // 50)); ids[k] = ids[(k + 1) % len(ids)]
+        if rng.random() < 0.4:  # ids in no order (hashes: an odd multiplier keeps equal ids equal and different ones different)
+            ids = ids * np.uint64(0x9E3779B97F4A7C15)
+        elif rng.random() < 0.3:  # serials that start over in every structure
+            ids = np.concatenate([np.arange(1, len(p[0]) + 1, dtype=np.uint64) for p in parts]) if len(xyz) else ids
         use_ids = ids if rng.random() < 0.8 else None
         n_points = int(rng.choice([1, 20, 64, 100, 100, 100, 103, 110, 128, 131, 200, 960, 1000, 1003]))
         probe = float(rng.choice([1.4, 1.4, 1.4, 0.0, 0.7, 2.5]))
