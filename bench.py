@@ -489,7 +489,7 @@ def per_call_leg(batch, n_points, seconds):
             f.write(np.uint32(b.n_structures).tobytes())
             f.write(b.structure_offsets.astype(np.uint32).tobytes())
             f.write(atoms.tobytes())
-        p = subprocess.run([exe, path, str(n_points), str(seconds), "1", "16"], capture_output=True, text=True, timeout=300)
+        p = subprocess.run([exe, path, str(n_points), str(seconds), "1", "16", "c16", "c64", "s64"], capture_output=True, text=True, timeout=300)
         if p.returncode != 0:
             return {"error": (p.stdout + p.stderr)[-300:]}
         legs = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -499,8 +499,13 @@ def per_call_leg(batch, n_points, seconds):
     return {"entry_point": "rsasa_calculate_sasa_internal (AoS rsasa_atom_t in, per-atom f32 out, pageable host buffers)",
             "structures_in_rotation": b.n_structures, "atoms_per_structure_median": int(np.median(sizes)),
             "atoms_per_structure_max": int(sizes.max()), "n_points": n_points,
-            "threads_1": next((x for x in legs if x.get("threads") == 1), None),
-            "threads_16": next((x for x in legs if x.get("threads") == 16), None),
+            "threads_1": next((x for x in legs if x.get("threads") == 1 and x.get("mode") == "alone"), None),
+            "threads_16": next((x for x in legs if x.get("threads") == 16 and x.get("mode") == "alone"), None),
+            "combined": {"threads_16": next((x for x in legs if x.get("threads") == 16 and x.get("mode") == "combined"), None),
+                         "threads_64": next((x for x in legs if x.get("threads") == 64 and x.get("mode") == "combined"), None),
+                         "threads_64_one_shared_context": next((x for x in legs if x.get("mode") == "combined_shared_context"), None),
+                         "definition": "the same calls with rsasa_context_set_call_combining(ctx, 0) on every context: calls "
+                                       "that arrive together are merged into batch launches inside the library (csrc/combine.cpp)"},
             "definition": "one structure per call, one context per host thread, all on this GPU; the threads draw "
                           "structures from one shared counter for the leg's duration; every call timed (p50 / p99)"}
 

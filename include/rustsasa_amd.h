@@ -32,8 +32,10 @@ extern "C" {
  * "the" batch); rsasa_batch_wait_all, rsasa_context_get_simd_width, rsasa_context_bind_thread added.
  * 3: rsasa_host_batch_enqueue / _wait / _wait_all (a stream of host batches), rsasa_context_clone_settings,
  *    rsasa_context_ids_dropped added;
- * nothing changed or removed. */
-#define RSASA_ABI_VERSION 3
+ * 4: rsasa_context_set_call_combining, rsasa_call_combining_stats added; rsasa_host_batch_enqueue with eight batches
+ *    queued returns RSASA_ERR_QUEUE_FULL at once (it used to wait for the oldest batch and then fail);
+ * nothing else changed, nothing removed. */
+#define RSASA_ABI_VERSION 4
 
 typedef enum rsasa_status {
     RSASA_OK = 0,
@@ -42,7 +44,8 @@ typedef enum rsasa_status {
     RSASA_ERR_HIP = -3,              /* a HIP runtime call failed; see rsasa_context_last_error */
     RSASA_ERR_OUT_OF_MEMORY = -4,
     RSASA_ERR_GRID_TOO_LARGE = -5,   /* a structure's cell grid exceeds 2^31 cells (coordinates too sparse) */
-    RSASA_ERR_INTERNAL = -6
+    RSASA_ERR_INTERNAL = -6,
+    RSASA_ERR_QUEUE_FULL = -7        /* rsasa_host_batch_enqueue: eight batches are queued and not yet waited for */
 } rsasa_status;
 
 /* Mirrors `Atom` (reference src/structures/atomic.rs:13-24) without the
@@ -79,6 +82,32 @@ int rsasa_context_get_device(const rsasa_context_t *ctx, int *out_device);
  * remainder rule -- unfused dot product and `<=` (src/lib.rs:163-218). */
 int rsasa_context_set_simd_width(rsasa_context_t *ctx, int simd_width);
 int rsasa_context_get_simd_width(rsasa_context_t *ctx, int *out_simd_width);
+
+/* CALL COMBINING (ABI 4), for the reference's own call pattern left unchanged:
+ * one rsasa_calculate_sasa_internal / rsasa_calculate_sasa_soa call per
+ * structure from every worker thread (reference src/main.rs:375,439,
+ * src/lib.rs:249-254).  With max_wait_us >= 0 the per-structure calls made
+ * through this context - from any number of host threads, and together with
+ * those of every other context of the same GPU that has it on - are merged into
+ * batch launches: a caller that finds one of the GPU's two combining lanes free
+ * leads a batch of every call queued at that moment with the same settings
+ * (probe radius, point count, lane count W, ids passed or not; calls that
+ * differ are never merged), every member copies its own atoms in and its own
+ * values out.  While both lanes are busy the arriving calls queue up, so the
+ * batches grow with the load and no timer is needed: max_wait_us = 0 is the
+ * recommended setting; a positive value lets a leader hold its batch back up
+ * to that long for as many calls as the previous batch had.  The values are
+ * those of the call made alone, bit for bit (a batch is independent
+ * structures).  A call the combiner does not take - more than 32 768 atoms,
+ * non-finite input, anything the call alone would report as an error - runs
+ * by itself and cannot fail its batch-mates; a device error fails every call
+ * of the batch it hit with that status.  A context may be shared by all
+ * threads or there may be one per thread.  max_wait_us < 0 switches it off
+ * (the default). */
+int rsasa_context_set_call_combining(rsasa_context_t *ctx, int max_wait_us);
+/* Batches launched and calls merged into them on `device` since the process
+ * started (either pointer may be NULL). */
+int rsasa_call_combining_stats(int device, uint64_t *out_batches, uint64_t *out_calls);
 
 /* Multi-socket hosts: binds the CALLING thread to the CPUs of the NUMA node the
  * context's GPU hangs off (sysfs numa_node / local_cpulist of its PCI address;
@@ -160,7 +189,10 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
  * on the caller's GPU, created by the first call (their workspaces and pinned
  * staging are sized like the caller's own would be, and live until
  * rsasa_context_destroy) - with the caller's settings at the time of the
- * enqueue; up to eight may be queued and not yet waited for.
+ * enqueue; up to eight may be queued and not yet waited for: a ninth enqueue
+ * does not block and does not take the batch - it returns RSASA_ERR_QUEUE_FULL
+ * at once (nothing of the call's buffers is touched; call rsasa_host_batch_wait
+ * and enqueue again).
  * rsasa_host_batch_wait() returns the OLDEST enqueued batch: it blocks until
  * that batch is complete and returns its status (the message is then the
  * context's last error); with nothing enqueued it returns RSASA_OK at once.

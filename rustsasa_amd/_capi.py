@@ -21,6 +21,7 @@ RSASA_ERR_HIP = -3
 RSASA_ERR_OUT_OF_MEMORY = -4
 RSASA_ERR_GRID_TOO_LARGE = -5
 RSASA_ERR_INTERNAL = -6
+RSASA_ERR_QUEUE_FULL = -7
 
 # numpy image of rsasa_atom_t (mirrors `Atom`, reference src/structures/atomic.rs:13-24)
 ATOM_DTYPE = np.dtype([("position", np.float32, (3,)), ("radius", np.float32), ("id", np.uint64)],
@@ -90,6 +91,8 @@ SYMBOLS = {
     "rsasa_context_enable_timing": (C.c_int, [_vp, C.c_int]),
     "rsasa_context_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
     "rsasa_context_ids_dropped": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "rsasa_context_set_call_combining": (C.c_int, [_vp, C.c_int]),
+    "rsasa_call_combining_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rsasa_sphere_points": (C.c_int, [C.c_size_t, _vp, _vp, _vp]),
 }
 

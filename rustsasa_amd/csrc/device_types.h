@@ -206,6 +206,9 @@ bool occlusion_uses_mx(const OcclusionTuning &tune, const Lattice &lat, uint32_t
 // The general kernel over the atoms the straight-line kernel deferred (see BatchView::defer_flag).
 void launch_occlusion_deferred(const BatchView &b, const Lattice &lat, hipStream_t stream);
 void launch_residue_sums(const BatchView &b, hipStream_t stream);
+// Pinned 24-byte atom records (x, y, z, r, id) -> device columns, and `hdr_bytes` of header beside them (combine.cpp).
+void launch_unpack_atoms(const void *records, uint32_t n_atoms, float *x, float *y, float *z, float *r, uint64_t *id,
+                         const void *hdr_src, void *hdr_dst, uint32_t hdr_bytes, hipStream_t stream);
 void launch_expand_frames(const float *xyz, const float *radius, const uint64_t *id,
                           const uint32_t *res_off, uint32_t n_atoms, uint32_t n_frames, uint32_t res_stride,
                           float *x, float *y, float *z, float *r, uint64_t *id_out,

@@ -3,7 +3,11 @@
 // with a context of its own - what the reference's directory mode does from every rayon worker (src/main.rs:375,439).
 // bench.py's `per_call` leg runs this as a child process (no interpreter lock between the threads).
 //
-//   bench_per_call <structures.bin> <n_points> <seconds per leg> <threads> [<threads> ...]
+//   bench_per_call <structures.bin> <n_points> <seconds per leg> <leg> [<leg> ...]
+//
+// A leg is a thread count T (a context per thread, every call by itself - the figures of round 5), cT (call combining on,
+// rsasa_context_set_call_combining: a context per thread) or sT (call combining on, ONE context shared by all threads);
+// PER_CALL_COMBINE_WAIT_US (default 0) is the max_wait_us of the combining legs.
 //
 // structures.bin: u32 n_structures, u32 offsets[n + 1], then rsasa_atom_t records (24 bytes each).  The threads take
 // structures from one shared counter (cycling through the list) until the leg's time is up; every call is timed.
@@ -35,10 +39,18 @@ int main(int argc, char **argv)
     for (uint32_t s = 0; s < n; s++) longest = std::max(longest, off[s + 1] - off[s]);
 
     for (int a = 4; a < argc; a++) {
-        const int nt = std::max(1, std::atoi(argv[a]));
+        const char mode = argv[a][0] == 'c' || argv[a][0] == 's' ? argv[a][0] : 'n';
+        const int nt = std::max(1, std::atoi(argv[a] + (mode == 'n' ? 0 : 1)));
+        const char *wv = std::getenv("PER_CALL_COMBINE_WAIT_US");
+        const int wait_us = wv ? std::atoi(wv) : 0;
         std::vector<rsasa_context_t *> ctxs(nt, nullptr);
-        for (auto &c : ctxs)
-            if (rsasa_context_create(0, &c) != RSASA_OK) { std::fprintf(stderr, "rsasa_context_create failed\n"); return 70; }
+        for (int t = 0; t < nt; t++) {
+            if (mode == 's' && t > 0) { ctxs[t] = ctxs[0]; continue; }
+            if (rsasa_context_create(0, &ctxs[t]) != RSASA_OK) { std::fprintf(stderr, "rsasa_context_create failed\n"); return 70; }
+            if (mode != 'n' && rsasa_context_set_call_combining(ctxs[t], wait_us) != RSASA_OK) return 70;
+        }
+        uint64_t cb0 = 0, cc0 = 0, cb1 = 0, cc1 = 0;
+        (void)rsasa_call_combining_stats(0, &cb0, &cc0);
         std::vector<std::vector<float>> outs(nt, std::vector<float>(longest));
         std::vector<std::vector<float>> lat(nt);
         std::vector<double> total(nt, 0.0);
@@ -69,12 +81,16 @@ int main(int argc, char **argv)
         std::vector<float> all;
         for (auto &v : lat) all.insert(all.end(), v.begin(), v.end());
         std::sort(all.begin(), all.end());
-        for (auto c : ctxs) rsasa_context_destroy(c);
+        (void)rsasa_call_combining_stats(0, &cb1, &cc1);
+        for (int t = 0; t < nt; t++)
+            if (mode != 's' || t == 0) rsasa_context_destroy(ctxs[t]);
         if (failed || all.empty()) { std::printf("{\"threads\":%d,\"error\":\"%d calls failed\"}\n", nt, failed.load()); continue; }
         auto q = [&](double p) { return all[std::min(all.size() - 1, (size_t)(p * (double)all.size()))]; };
-        std::printf("{\"threads\":%d,\"calls\":%zu,\"seconds\":%.3f,\"structures_per_s\":%.1f,\"atoms_per_s\":%.1f,"
-                    "\"ms_per_call_p50\":%.4f,\"ms_per_call_p99\":%.4f,\"ms_per_call_max\":%.4f}\n",
-                    nt, all.size(), dt, (double)all.size() / dt, (double)atoms_done.load() / dt, q(0.50), q(0.99), all.back());
+        std::printf("{\"threads\":%d,\"mode\":\"%s\",\"calls\":%zu,\"seconds\":%.3f,\"structures_per_s\":%.1f,\"atoms_per_s\":%.1f,"
+                    "\"ms_per_call_p50\":%.4f,\"ms_per_call_p99\":%.4f,\"ms_per_call_max\":%.4f,\"combined_batches\":%llu,\"calls_per_batch\":%.2f}\n",
+                    nt, mode == 'n' ? "alone" : mode == 'c' ? "combined" : "combined_shared_context", all.size(), dt, (double)all.size() / dt,
+                    (double)atoms_done.load() / dt, q(0.50), q(0.99), all.back(), (unsigned long long)(cb1 - cb0),
+                    cb1 > cb0 ? (double)(cc1 - cc0) / (double)(cb1 - cb0) : 0.0);
     }
     return 0;
 }

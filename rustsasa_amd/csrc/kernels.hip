@@ -119,7 +119,14 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
 template <uint32_t SLOTS, uint32_t THREADS, bool LARGE>
 __global__ __launch_bounds__(THREADS) void k_ids_distinct(BatchView b)
 {
-    if (b.status->ids_unordered == 0u || b.status->ids_needed != 0u) return;
+    // The way out is taken by the WHOLE workgroup or by none of it: other workgroups of this launch raise ids_needed while
+    // this one runs, so waves that read the flags for themselves could part ways - some gone without having zeroed their
+    // share of the table, the others past the barrier with those slots holding whatever the LDS held (and then following
+    // a garbage entry far outside the id column).  One thread reads the flags, everybody reads its verdict.
+    __shared__ uint32_t s_go;
+    if (threadIdx.x == 0u) s_go = (b.status->ids_unordered != 0u && b.status->ids_needed == 0u) ? 1u : 0u;
+    __syncthreads();
+    if (s_go == 0u) return;
     if (b.ids_too_big) {
         if (blockIdx.x == 0u && threadIdx.x == 0u) b.status->ids_needed = 1u;
         return;
@@ -138,6 +145,9 @@ __global__ __launch_bounds__(THREADS) void k_ids_distinct(BatchView b)
         for (;;) {
             const uint32_t there = atomicCAS(&s_tab[h], 0u, i + 1u);
             if (there == 0u) break;
+            // (second guard: an entry is the number of one of this structure's atoms, or the slot counts as the batch's
+            // "ids stay in play" - never an address)
+            if (there > n) { equal = true; break; }
             if (id[there - 1u] == mine) { equal = true; break; }
             h = h + 1u == SLOTS ? 0u : h + 1u;
         }
@@ -868,6 +878,35 @@ void launch_expand_frames(const float *xyz, const float *radius, const uint64_t 
     const uint64_t n = std::max<uint64_t>((uint64_t)n_atoms * n_frames, (uint64_t)res_stride * n_frames + 1);
     hipLaunchKernelGGL(k_expand_frames, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, xyz,
                        radius, id, res_off, n_atoms, n_frames, res_stride, x, y, z, r, id_out, res_out);
+}
+
+// The call combiner's batches (combine.cpp): the callers' atoms sit in pinned host memory as 24-byte records
+// (x, y, z, r, id: rsasa_atom_t), the batch's header (status, grids, binning work list) beside them.  One launch reads
+// both across the link - every thread one record, coalesced, thousands of reads in flight - and writes the columns and
+// the header into device memory: no copy engine involved (a hipMemcpyAsync costs the stream 15 us before the first
+// kernel starts; the binning kernel reading the pinned columns itself, one structure per workgroup, took 70 us).
+__global__ __launch_bounds__(256) void k_unpack_atoms(const uint2 *__restrict__ rec, uint32_t n, float *__restrict__ x, float *__restrict__ y,
+                                                      float *__restrict__ z, float *__restrict__ r, uint64_t *__restrict__ id,
+                                                      const uint32_t *__restrict__ hdr_src, uint32_t *__restrict__ hdr_dst, uint32_t hdr_words)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < hdr_words) hdr_dst[i] = hdr_src[i];
+    if (i >= n) return;
+    const uint2 a = rec[3u * i], b = rec[3u * i + 1u], c = rec[3u * i + 2u];
+    x[i] = __uint_as_float(a.x);
+    y[i] = __uint_as_float(a.y);
+    z[i] = __uint_as_float(b.x);
+    r[i] = __uint_as_float(b.y);
+    if (id) id[i] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+}
+
+void launch_unpack_atoms(const void *records, uint32_t n_atoms, float *x, float *y, float *z, float *r, uint64_t *id,
+                         const void *hdr_src, void *hdr_dst, uint32_t hdr_bytes, hipStream_t stream)
+{
+    const uint32_t words = hdr_bytes / 4u, threads = std::max(n_atoms, words);
+    if (!threads) return;
+    hipLaunchKernelGGL(k_unpack_atoms, dim3(cdiv(threads, 256u)), dim3(256), 0, stream, (const uint2 *)records, n_atoms, x, y, z, r, id,
+                       (const uint32_t *)hdr_src, (uint32_t *)hdr_dst, words);
 }
 
 void launch_residue_sums(const BatchView &b, hipStream_t stream)

@@ -103,6 +103,18 @@ class Context:
     def set_simd_width(self, w: int):
         self._check(self._lib.rsasa_context_set_simd_width(self._h, w))
 
+    def set_call_combining(self, max_wait_us: int = 0):
+        """rsasa_context_set_call_combining: per-structure calls of several host threads (ctypes releases the interpreter
+        lock during a call) are merged into batch launches; max_wait_us < 0 switches it off."""
+        self._check(self._lib.rsasa_context_set_call_combining(self._h, int(max_wait_us)))
+
+    @staticmethod
+    def call_combining_stats(device: int = 0):
+        """(batches launched, calls merged into them) on `device` since the process started."""
+        b, c = C.c_uint64(0), C.c_uint64(0)
+        check(_capi.load().rsasa_call_combining_stats(device, C.byref(b), C.byref(c)), None)
+        return int(b.value), int(c.value)
+
     # ---- single structure -------------------------------------------------
     def calculate_sasa_internal(self, atoms: np.ndarray, probe_radius: float = 1.4,
                                 n_points: int = 100, threads: int = -1) -> np.ndarray:

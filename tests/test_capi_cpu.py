@@ -27,7 +27,7 @@ def test_header_symbols_are_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/rustsasa_amd.h but not exported"
     assert set(names) == set(_capi.SYMBOLS), set(names) ^ set(_capi.SYMBOLS)
-    assert lib.rsasa_abi_version() == 3
+    assert lib.rsasa_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

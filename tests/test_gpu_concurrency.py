@@ -256,3 +256,115 @@ def test_measurement_switches_are_read_only_under_rsasa_tuning():
         totals[tuning] = [ln for ln in p.stdout.splitlines() if ln.startswith("TOTAL")][0]
         assert ("h2h ctx" in p.stderr) == (tuning == "1"), p.stderr[-500:]
     assert totals["0"] == totals["1"]
+
+
+def test_call_combining_merges_concurrent_calls_and_keeps_every_value():
+    """rsasa_context_set_call_combining (ABI 4): 32 host threads make the reference's own call - one structure per call
+    (src/main.rs:375,439, src/lib.rs:249-254) - with mixed structure sizes, lane counts W, point counts and entry points
+    (AoS records, columns with ids, columns without), through one shared context and through contexts of their own.
+    Calls with different settings must never be merged, so every value must equal the oracle run with THAT call's
+    settings; a call with unusable input fails alone, a call with NaN input (defined: the oracle's values) computes
+    alone, and neither disturbs the calls merged around it; the counters say that merging did happen."""
+    import rustsasa_amd
+    from rustsasa_amd import RsasaError
+    proteome = bw.synthetic_proteome(48, seed=11)
+    sizes = np.diff(proteome.structure_offsets.astype(np.int64))
+    pick = np.argsort(sizes)[[0, 5, 12, 20, 28, 36, 44, 47]]  # 150 .. ~10 000 atoms
+    structs = [tuple(np.ascontiguousarray(a) for a in proteome.structure(int(s))) for s in pick]
+    x0, y0, z0, r0, i0 = structs[2]
+    nan_case = (np.where(np.arange(len(x0)) == 7, np.float32(np.nan), x0), y0, z0, r0, i0)
+    inf_x = x0.copy()
+    inf_x[3] = np.inf
+    settings = [(8, 100), (16, 100), (4, 97), (8, 200)]  # (W, points): 100 % 16 = 4 and 97 % 4 = 1 remainder points
+    want = {}
+    for k, (w, n) in enumerate(settings):
+        for s, (x, y, z, r, ids) in enumerate(structs):
+            want[(k, s, True)] = po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n, w)
+            if k == 0:
+                want[(k, s, False)] = po.calculate_sasa_internal(x, y, z, r, None, PROBE, n, w)
+    want_nan = po.calculate_sasa_internal(*nan_case, PROBE, 100, 8)
+    shared = rustsasa_amd.Context(0)
+    shared.set_call_combining(0)
+    own = {}
+    errors, done = [], []
+    b0, c0 = rustsasa_amd.Context.call_combining_stats(0)
+
+    def work(tid):
+        try:
+            k = tid % 4
+            w, n = settings[k]
+            if k == 0:
+                c = shared  # eight threads on one context
+            else:
+                c = own[tid] = rustsasa_amd.Context(0)
+                c.set_simd_width(w)
+                c.set_call_combining(20 if tid % 8 == k else 0)
+            for it in range(24):
+                s = (tid * 3 + it) % len(structs)
+                x, y, z, r, ids = structs[s]
+                if tid == 4 and it % 6 == 0:  # unusable input: this call's error, nobody else's
+                    try:
+                        c.calculate_sasa_soa(inf_x, y0, z0, r0, i0, PROBE, n)
+                        errors.append((tid, it, "an infinite coordinate was accepted"))
+                    except RsasaError as e:
+                        if e.status != -5:
+                            errors.append((tid, it, f"status {e.status}"))
+                    continue
+                if tid == 8 and it % 5 == 0:  # NaN input: defined, computed by the call alone
+                    got = c.calculate_sasa_soa(*nan_case, PROBE, 100)
+                    if not np.array_equal(got, want_nan, equal_nan=True):
+                        errors.append((tid, it, "NaN case"))
+                    continue
+                with_ids = not (k == 0 and tid % 8 == 4)
+                if tid % 2 == 0 and with_ids:
+                    got = c.calculate_sasa_internal(rustsasa_amd.make_atoms(x, y, z, r, ids), PROBE, n)
+                else:
+                    got = c.calculate_sasa_soa(x, y, z, r, ids if with_ids else None, PROBE, n)
+                if not np.array_equal(got, want[(k, s, with_ids)]):
+                    errors.append((tid, it, s, int(np.sum(got != want[(k, s, with_ids)]))))
+            done.append(tid)
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(32)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a combined call hangs"
+    b1, c1 = rustsasa_amd.Context.call_combining_stats(0)
+    for c in own.values():
+        c.close()
+    shared.close()
+    assert errors == [] and len(done) == 32
+    assert c1 - c0 > 0 and b1 - b0 < c1 - c0, f"{c1 - c0} calls in {b1 - b0} batches: nothing was merged"
+    # switched off again, a context's calls run by themselves
+    with rustsasa_amd.Context(0) as c:
+        c.set_call_combining(0)
+        c.set_call_combining(-1)
+        x, y, z, r, ids = structs[1]
+        assert np.array_equal(c.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100), want[(0, 1, True)])
+        assert rustsasa_amd.Context.call_combining_stats(0) == (b1, c1)
+
+
+def test_ninth_host_batch_is_refused_at_once():
+    """Eight host batches may be queued and not yet waited for; a ninth rsasa_host_batch_enqueue returns
+    RSASA_ERR_QUEUE_FULL without blocking and without touching the queue (ABI 4; it used to wait for the oldest batch
+    and then fail), and after one wait there is room again."""
+    import time
+    import rustsasa_amd
+    from rustsasa_amd import RsasaError
+    b = bw.synthetic_proteome(6, seed=9)
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+    with rustsasa_amd.Context(0) as ctx:
+        outs = [ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100)[0] for _ in range(8)]
+        time.sleep(0.5)  # (all eight are computed by now: the queue stays full until a wait takes one out)
+        t0 = time.perf_counter()
+        with pytest.raises(RsasaError) as e:
+            ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100)
+        assert e.value.status == -7 and time.perf_counter() - t0 < 0.2
+        ctx.host_batch_wait()
+        outs.append(ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100)[0])
+        ctx.host_batch_wait_all()
+        for o in outs:
+            assert np.array_equal(o, want)

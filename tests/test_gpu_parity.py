@@ -36,7 +36,7 @@ def example_vdw():
 def test_library_loaded_is_in_tree():
     from rustsasa_amd import _capi
     assert _capi.LIB_PATH.endswith("rustsasa_amd/lib/librustsasa_amd.so")
-    assert _capi.load().rsasa_abi_version() == 3
+    assert _capi.load().rsasa_abi_version() == 4
 
 
 def test_golden_vector_example_cif(ctx, example_vdw):
