@@ -69,8 +69,12 @@ def parse_args(argv=None):
                    help="timed steps of the secondary weak-scaling measurement at N > 1 (0 disables it)")
     p.add_argument("--config5-steps", type=int, default=30,
                    help="timed steps of the secondary 1M-atom / 960-point measurement (BASELINE.json configs[4]; 0 = skip)")
+    p.add_argument("--real-steps", type=int, default=10,
+                   help="steps of the real_coords leg (the reference's 88-file quality set, tiled to the proteome's size; 0: skip)")
     p.add_argument("--files", type=int, default=1000,
                    help="files of the secondary directory-mode measurement (files on /dev/shm -> residue values; 0 = skip)")
+    p.add_argument("--e2e-files", type=int, default=4363,
+                   help="files of the files_mode.end_to_end leg (files in -> one JSON file per input out, one call; 0: skip)")
     p.add_argument("--per-call-seconds", type=float, default=1.0,
                    help="seconds per leg of the secondary drop-in measurement: rsasa_calculate_sasa_internal once per "
                         "structure from 1 and from 16 host threads (0 = skip)")
@@ -418,7 +422,74 @@ def config5_leg(ctx, dev, steps, with_ids):
             "total_sasa": round(total, 1)}
 
 
-def files_leg(n_files):
+def real_coords_leg(ctx, dev, steps, n_points):
+    """The occlusion kernel on REAL, diverse coordinates: the 87 readable structures of the reference's quality set
+    (tests/golden/freesasa_set.tar.xz; the reader's selection, ProtOr radii, whole complexes, the reader's hashed ids)
+    tiled under rigid motions to the proteome batch's size (real_coords.py).  Device-resident stepping, two batches in
+    flight, kernel times from the library's HIP events; K from the kernel's own candidate counts; the grouping figures
+    (atoms per prologue, union overflow) from the CPU simulation of the kernel's rule on every fourth structure."""
+    import numpy as np
+    import torch
+    import bench_workloads as bw
+    import real_coords as rc
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sim_groups as sg
+    base = rc.quality_set_batch()
+    b = rc.tiled(base, 11_700_000)
+    run = DeviceRun(ctx, b, n_points, dev, True, None)
+    counts = torch.zeros(b.n_atoms, dtype=torch.int32, device=dev)
+    run.step(counts)   # (also the warm-up: workspace growth, the id tables switched on by ids in no order)
+    k = counts.cpu().numpy().astype(np.int64)
+    run.step()
+    run.enqueue(k=0)
+    for i in range(1, 3):
+        run.enqueue(k=i % 2)
+        ctx.wait()
+    ctx.wait()
+    ctx.enable_timing(True)
+    occl, n_def, cells = [], 0, 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run.enqueue(k=0)
+    for i in range(1, steps):
+        run.enqueue(k=i % 2)
+        ctx.wait()
+        occl.append(ctx.timings()["occlusion_ms"])
+    ctx.wait()
+    t = ctx.timings()
+    occl.append(t["occlusion_ms"])
+    n_def, cells = int(t["n_deferred"]), int(t["n_cells"])
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ctx.enable_timing(False)
+    grid = []
+    for _ in range(3):
+        ctx.enable_timing(True)
+        run.step()
+        grid.append(ctx.timings()["grid_build_ms"])
+        ctx.enable_timing(False)
+    total = float(run.outs[0][0].sum().item())
+    del run
+    alg = 20.0 * b.n_atoms + 16.0 * float(k.sum())
+    occ_ms = float(np.mean(occl))
+    sizes = np.diff(b.structure_offsets.astype(np.int64))
+    return {"workload": f"the reference's quality set (tests/quality.rs:200-258; {base.n_structures} real structures, {base.n_atoms} atoms: "
+                        f"reader's selection, ProtOr radii, hashed ids, whole complexes) x {b.n_structures // base.n_structures} rigid motions, "
+                        f"{n_points} points, probe {PROBE}",
+            "structures": b.n_structures, "atoms": b.n_atoms, "atoms_per_structure_median": int(np.median(sizes)),
+            "atoms_per_structure_max": int(sizes.max()), "steps": steps,
+            "ms_per_step": round(el / steps * 1e3, 4), "structures_per_s": round(b.n_structures * steps / el, 1),
+            "atoms_per_s": round(b.n_atoms * steps / el, 1),
+            "occlusion_ms": round(occ_ms, 4), "grid_build_ms": round(float(np.min(grid)), 4),
+            "algorithmic_bytes": alg, "frac": round(alg / (occ_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "candidates_per_atom": round(float(k.mean()), 2), "candidates_max": int(k.max()),
+            "n_deferred": n_def, "grid_cells_per_atom": round(cells / b.n_atoms, 2),
+            "ids_dropped_by_the_device_check": ctx.ids_dropped() > 0,
+            "grouping": sg.shipped_grouping(bw.select(base, np.arange(0, base.n_structures, 4))),
+            "total_sasa": round(total, 1)}
+
+
+def files_leg(n_files, e2e_files=4363):
     """Directory mode (reference src/main.rs:342-480): n synthetic PDB files on /dev/shm -> per-residue values through
     the C++ host API's process_files (sasa_host_cli, its own process: parse threads + GPU batches), three calls in one
     process; then the same structures as AlphaFold-style mmCIF files (`mmcif`: the format BASELINE.json's config names).
@@ -461,6 +532,20 @@ def files_leg(n_files):
     r = one("pdb")
     if "error" in r:
         return r
+
+    def e2e(fmt):
+        # files in -> one JSON file per input out, ONE call over the whole 4 363-file set (tools/bench_files.py --end-to-end:
+        # a child process that writes the set with a pool of processes and runs the C++ driver; this process holds the GPU)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_files.py"), "--end-to-end", "--files", str(e2e_files),
+                            "--format", fmt, "--repeat", "1"], capture_output=True, text=True, timeout=900)
+        if p.returncode != 0:
+            return {"error": (p.stdout + p.stderr)[-300:]}
+        return json.loads(p.stdout.strip().splitlines()[-1])
+
+    if e2e_files > 0:
+        r["end_to_end"] = e2e("pdb")
+        if "error" not in r["end_to_end"]:
+            r["end_to_end"]["mmcif"] = e2e("cif")
     r.update({"host_threads": os.cpu_count(), "mmcif": one("cif"),
               "note": "files_per_s: the first process_files call of a fresh process (HIP start-up inside); later calls "
                       "of the same process: files_per_s_later_calls; PDB text on /dev/shm, parse + selection + GPU + "
@@ -717,6 +802,28 @@ def main():
                "residues_equal_hbm_run": bool(sync_equal and np.array_equal(hres, got_res)
                                               and np.array_equal(h2h_out2[0], got_res)),
                "stream": stream_leg, "one_call_at_a_time": one}
+        if h2h_arrays[4] is not None and rank == 0 and world == 1:
+            # the same stream with the ids as SASAOptions::process passes them (options.rs:183: 64-bit hashes, in no order): the
+            # host cannot prove hashes different with one comparison per atom, so 32-bit folds cross the link and the id
+            # rule stays in the kernels
+            hid_sorted = h2h_arrays[4].copy()
+            h2h_arrays[4][:] = hid_sorted * np.uint64(0x9E3779B97F4A7C15)
+            try:
+                n0 = ctx.ids_dropped()
+                h2h_stream(n_stream)
+                hr = []
+                for _ in range(3):
+                    hr.append(timed(dist, 1, lambda: h2h_stream(n_stream)))
+                hm = sorted(hr)[1]
+                h2h["ids_as_hashes"] = {
+                    "ms_per_step": round(hm / n_stream * 1e3, 4), "value": round(batch.n_structures * n_stream / hm, 2),
+                    "steps": n_stream, "ms_per_step_runs": [round(t / n_stream * 1e3, 4) for t in hr],
+                    "residues_equal_hbm_run": bool(np.array_equal(hres, got_res) and np.array_equal(h2h_out2[0], got_res)),
+                    "sub_batches_run_without_ids": ctx.ids_dropped() - n0,
+                    "definition": "the stream of host batches with the id column replaced by 64-bit hashes in no order (pinned): "
+                                  "what SASAOptions::process and process_files hand to the hot path"}
+            finally:
+                h2h_arrays[4][:] = hid_sorted
 
     # ---- secondary: one batch at a time (enqueue, wait, enqueue, ...): what a caller with a single batch sees ----
     two = None
@@ -794,10 +901,17 @@ def main():
     config5 = None
     if rank == 0 and world == 1 and args.workload == "proteome" and args.config5_steps > 0 and not shard_of:
         config5 = config5_leg(ctx, dev, args.config5_steps, not args.no_ids)
+    # ---- secondary (rank 0, one GPU): the same kernels on real, diverse coordinates (the reference's quality set, tiled) ----
+    real = None
+    if rank == 0 and world == 1 and args.workload == "proteome" and args.real_steps > 0 and not shard_of:
+        try:
+            real = real_coords_leg(ctx, dev, args.real_steps, n_points)
+        except Exception as e:  # noqa: BLE001 (a leg of its own: the line is printed without it)
+            real = {"error": repr(e)[:300]}
     # ---- secondary (rank 0, one GPU): directory mode, files on disk -> per-residue values (C++ process_files) ----
     files_mode = None
     if rank == 0 and world == 1 and args.workload == "proteome" and args.files > 0 and not shard_of:
-        files_mode = files_leg(args.files)
+        files_mode = files_leg(args.files, args.e2e_files)
 
     # ---- secondary (rank 0, one GPU): the drop-in call per structure, from 1 and 16 host threads ----
     per_call = None
@@ -900,6 +1014,8 @@ def main():
             line["host_to_host"] = h2h
         if config5:
             line["config5"] = config5
+        if real:
+            line["real_coords"] = real
         if files_mode:
             line["files_mode"] = files_mode
         if per_call:

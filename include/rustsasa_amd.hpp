@@ -179,6 +179,11 @@ struct OptionValues {
     // process_files only: one GPU worker thread per context (one context per GPU), fed from a queue
     // of parsed chunks.  Empty = {context}.
     std::vector<rsasa_context_t *> contexts;
+    // process_files only: when set, every file's result is ALSO written to <output_dir>/<file stem>.json in serde's shape
+    // (sasa_result_to_json) - the reference's directory mode end to end (src/main.rs:203-226,395-403: one output file
+    // per input) -, by the threads that build the results, beside the GPU workers.  The directory must exist.  A file
+    // that cannot be written is that file's error.
+    std::string output_dir;
 };
 
 // Wall-clock split of SASAOptions::process_files.
@@ -187,6 +192,7 @@ struct FilesTimings {
     double compute_seconds = 0;  // packing, H2D, GPU hot path, D2H, result mapping (GPU workers, summed; overlaps parsing)
     double total_seconds = 0;
     std::size_t n_files = 0, n_atoms = 0;
+    std::uint64_t bytes_written = 0;  // JSON written to OptionValues::output_dir
     std::vector<int> worker_simd_widths;  // the pulp lane count every GPU worker's context ran with (the caller's, on each)
 };
 
@@ -243,6 +249,8 @@ public:
     SASAOptions &with_context(rsasa_context_t *ctx) { o_.context = ctx; return *this; }
     // directory mode over several GPUs: one context per device (rsasa_context_create(device, ...))
     SASAOptions &with_contexts(std::vector<rsasa_context_t *> ctxs) { o_.contexts = std::move(ctxs); return *this; }
+    // directory mode end to end: per-file JSON into `dir` (OptionValues::output_dir)
+    SASAOptions &with_output_dir(std::string dir) { o_.output_dir = std::move(dir); return *this; }
     const OptionValues &values() const { return o_; }
 
     // options.rs:606-618

@@ -64,6 +64,7 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     unsigned threads = 0;
     size_t batch = 0;
     bool full = false;
+    std::string out_dir;
     int workers = 0, devices = 1;  // --workers K: K GPU worker contexts, on devices k % --devices
     int calls = 1;                 // --calls N: process_files N times in this process (the last call's results are printed)
     int simd_width = 0;            // --simd-width W: the pulp lane count of the context(s) the call is given (0: default)
@@ -75,6 +76,7 @@ static int run_files(int argc, char **argv, PrintOne print_one)
         if (!std::strcmp(argv[i], "--calls") && i + 1 < argc) calls = std::max(1, std::atoi(argv[i + 1]));
         if (!std::strcmp(argv[i], "--simd-width") && i + 1 < argc) simd_width = std::atoi(argv[i + 1]);
         if (!std::strcmp(argv[i], "--full")) full = true;
+        if (!std::strcmp(argv[i], "--out-dir") && i + 1 < argc) out_dir = argv[i + 1];  // per-file JSON (OptionValues::output_dir)
     }
     std::vector<rsasa_context_t *> ctxs;
     for (int k = 0; k < workers; k++) {
@@ -91,6 +93,7 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     FilesTimings t;
     auto opts = make<L>(argc - 1, argv + 1);
     if (!ctxs.empty()) opts.with_contexts(ctxs);
+    if (!out_dir.empty()) opts.with_output_dir(out_dir);
     auto res = opts.process_files(paths, threads, batch, &t);
     std::string call_s = std::to_string(t.total_seconds);  // every call's wall time: the first one includes the HIP runtime's start-up
     for (int k = 1; k < calls; k++) {
@@ -102,8 +105,9 @@ static int run_files(int argc, char **argv, PrintOne print_one)
     for (const auto &r : res) n_ok += r.ok();
     std::string widths;
     for (int w : t.worker_simd_widths) widths += (widths.empty() ? "" : ",") + std::to_string(w);
-    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"calls_s\":[%s],\"worker_simd_widths\":[%s],\"results\":[",
-                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds, call_s.c_str(), widths.c_str());
+    std::printf("{\"n_files\":%zu,\"n_ok\":%zu,\"n_atoms\":%zu,\"parse_s\":%.6f,\"compute_s\":%.6f,\"total_s\":%.6f,\"calls_s\":[%s],\"worker_simd_widths\":[%s],\"bytes_written\":%llu,\"results\":[",
+                t.n_files, n_ok, t.n_atoms, t.parse_seconds, t.compute_seconds, t.total_seconds, call_s.c_str(), widths.c_str(),
+                (unsigned long long)t.bytes_written);
     for (size_t i = 0; i < res.size(); i++) {
         std::printf("%s", i ? "," : "");
         if (!res[i].ok()) {
@@ -177,6 +181,17 @@ int main(int argc, char **argv)
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::printf("{\"reps\":%d,\"atoms\":%zu,\"ms_per_file\":%.4f,\"ns_per_atom\":%.1f}\n", reps,
                     atoms / (size_t)reps, s / reps * 1e3, s / (double)atoms * 1e9);
+        return 0;
+    }
+    if (argc >= 2 && std::string(argv[1]) == "json-floats") {  // test hook: the JSON writer's f32 printing (no GPU)
+        std::vector<float> v;
+        for (int i = 2; i < argc; i++) {
+            const uint32_t bits = (uint32_t)std::strtoul(argv[i], nullptr, 16);
+            float f;
+            std::memcpy(&f, &bits, 4);
+            v.push_back(f);
+        }
+        std::printf("%s\n", sasa_result_to_json(v).c_str());
         return 0;
     }
     if (argc >= 4 && std::string(argv[1]) == "files") {

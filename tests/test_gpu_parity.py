@@ -1266,3 +1266,69 @@ def test_infinite_input_is_the_calls_error_and_the_context_lives_on(ctx, example
     assert e.value.status == _capi.RSASA_ERR_GRID_TOO_LARGE
     atom, _, _ = _device_run(ctx, b, want_k=False)
     assert np.array_equal(atom, po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0))
+
+
+def test_real_coordinates_tiled_batch_matches_the_oracle(ctx):
+    """bench.py's `real_coords` leg at test size: the reference's quality set (tests/quality.rs:200-258 - 87 real
+    structures as the reader selects them: whole complexes of up to 32 500 atoms, ProtOr radii, the reader's hashed ids
+    in no order) plus two copies of it under rigid motions (real_coords.tiled: 1.37 M atoms, 261 structures), through
+    the device-resident batch path - the default k_occlusion_mx dispatch with the id tables - against the oracle:
+    every atom, every candidate count, every chain sum; then once more, as the second batch of the context (the id
+    tables are only part of a batch once the context has seen ids in no order)."""
+    import real_coords as rc
+    base = rc.quality_set_batch()
+    assert base.n_structures == 87 and base.n_atoms > 450_000
+    b = rc.tiled(base, 3 * base.n_atoms, seed=7)
+    assert b.n_structures == 3 * 87
+    want, _, want_k = None, None, None
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+    for _ in range(2):
+        atom, res, k = _device_run(ctx, b)
+        bad = np.flatnonzero(atom != want)
+        assert bad.size == 0, (bad.size, bad[:5], atom[bad[:5]], want[bad[:5]])
+        assert np.array_equal(res, po.residue_sums(want, b.residue_offsets))
+    # candidate counts of the files' own frame against the oracle's lists, structure by structure (a sample)
+    so = b.structure_offsets
+    for s in (0, 17, 40, 86):
+        x, y, z, r, ids = b.structure(s)
+        _, _, wk = po.calculate_sasa_internal(x, y, z, r, ids, PROBE, 100, 8, return_details=True)
+        assert np.array_equal(k[so[s]:so[s + 1]], wk)
+    assert 30.0 < k.mean() < 60.0
+
+
+def test_rank_shard_of_the_eight_way_split(ctx):
+    """BASELINE.json configs[3] at one rank's size: rank 0's shard of the 8-way largest-first split of the proteome
+    (bench.py --shard-of 8: 545 structures, 1.47 M atoms) - what every GPU of an 8-GPU node computes -, through the
+    device-resident stepping with two batches in flight (the way a rank steps) AND as a stream of host batches
+    (rsasa_host_batch_enqueue), every atom and residue against the oracle."""
+    import torch
+    full = bw.synthetic_proteome()
+    sizes = np.diff(full.structure_offsets.astype(np.int64))
+    parts = bw.shard_largest_first(sizes, 8)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(full.n_structures))
+    b = bw.select(full, parts[0])
+    assert b.n_structures == 545 and 1_400_000 < b.n_atoms < 1_550_000
+    want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+    want_res = po.residue_sums(want, b.residue_offsets)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    x, y, z, r, ids, ro = t(b.x), t(b.y), t(b.z), t(b.radius), t(b.ids.view(np.int64)), t(b.residue_offsets.view(np.int32))
+    outs = [(torch.full((b.n_atoms,), -1.0, dtype=torch.float32, device=dev),
+             torch.full((b.n_residues,), -1.0, dtype=torch.float32, device=dev)) for _ in range(2)]
+    torch.cuda.synchronize()
+    ctx.enqueue_device(x, y, z, r, ids, b.structure_offsets, outs[0][0], ro, outs[0][1], None, PROBE, 100)
+    for i in range(1, 6):  # step k + 1 is enqueued before step k is waited for
+        ctx.enqueue_device(x, y, z, r, ids, b.structure_offsets, outs[i % 2][0], ro, outs[i % 2][1], None, PROBE, 100)
+        ctx.wait()
+        a, rs = outs[(i - 1) % 2]
+        assert np.array_equal(a.cpu().numpy(), want) and np.array_equal(rs.cpu().numpy(), want_res)
+        a.fill_(-1.0)
+        rs.fill_(-1.0)
+    ctx.wait()
+    assert np.array_equal(outs[1][0].cpu().numpy(), want) and np.array_equal(outs[1][1].cpu().numpy(), want_res)
+    # the same shard as a stream of host batches: three enqueued, then collected oldest first
+    got = [ctx.host_batch_enqueue(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100,
+                                  residue_offsets=b.residue_offsets) for _ in range(3)]
+    ctx.host_batch_wait_all()
+    for a, rs in got:
+        assert np.array_equal(a, want) and np.array_equal(rs, want_res)

@@ -800,3 +800,62 @@ def test_process_files_with_nan_coordinates_in_one_file(tmp_path):
     atom, _, _ = expected(None, path=str(bad))
     clean, _, _ = expected("1jcd.pdb")
     assert np.sum(atom != clean) >= 1 and np.all(np.isfinite(atom))
+
+
+def test_json_writer_prints_f32_as_serde_does():
+    """sasa_result_to_json's numbers (io.rs:11-13 through serde_json / ryu): the shortest decimal that reads back as the
+    same f32, plain notation with ".0" on whole numbers, a bare exponent outside [1e-5, 1e16), null for non-finite
+    values.  (Round 5's writer printed 200.0 as 2e+02 and took 2.4 us per value; directory mode with per-file output
+    prints 1.5 M of them per proteome.)"""
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.uniform(0, 400, 300), rng.integers(0, 500, 60).astype(np.float64), 10.0 ** rng.uniform(-12, 20, 80),
+                           -rng.uniform(0, 50, 20), [0.0, 0.1, 200.0, 1e-5, 9.9999e-6, 1e16, 9.9e15, 16777216.0, 3.4028235e38, 1e-45]]
+                          ).astype(np.float32)
+    bits = [f"{b:08x}" for b in vals.view(np.uint32)] + ["7fc00000", "7f800000", "ff800000"]
+    out = subprocess.run([CLI, "json-floats"] + bits, capture_output=True, text=True).stdout.strip()
+    assert out.startswith('{"Atom":[') and out.endswith("]}")
+    toks = out[len('{"Atom":['):-2].split(",")
+    assert toks[-3:] == ["null", "null", "null"] and len(toks) == len(bits)
+    for v, t in zip(vals, toks):
+        assert np.float32(t) == v, (v, t)                                      # reads back as the same f32
+        m, e = np.format_float_scientific(v, unique=True, trim="-").split("e")   # the shortest digits and their exponent
+        if v == 0 or -5 <= int(e) < 16:  # (ryu: plain notation while the decimal point stays within the digits' reach)
+            assert t == np.format_float_positional(v, unique=True, trim="0"), (v, t)   # shortest, plain, ".0" on whole numbers
+        else:
+            assert t == f"{m}e{int(e)}", (v, t)                                 # "1e-7", "1.5e20"
+    assert [np.float32(x) for x in json.loads(out.replace("null", "0"))["Atom"][:3]] == [v for v in vals[:3]]
+
+
+@pytest.mark.gpu
+def test_directory_mode_end_to_end_writes_one_json_per_file(tmp_path):
+    """The reference's directory mode end to end (src/main.rs:203-226,342-480, src/utils/io.rs:11-13): files in, one
+    <stem>.json per input in the output directory, in serde's shape, with the values process_files returns; a file
+    that cannot be read gets no output and does not disturb the others; PDB and mmCIF inputs side by side."""
+    names = ["1jcd.pdb", "2drt.pdb", "151L_H3.pdb", "example.cif", "bad_seqadv_1A06.pdb"]
+    paths = [sio.data_path(n) for n in names] + [str(tmp_path / "missing.pdb")]
+    lst = tmp_path / "files.txt"
+    lst.write_text("\n".join(paths) + "\n")
+    out_dir = tmp_path / "out"
+    out_dir.mkdir()
+    p = subprocess.run([CLI, "files", "residue", str(lst), "--full", "--labels", "--out-dir", str(out_dir)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[:400]
+    got = json.loads(p.stdout)
+    assert got["n_ok"] == len(names) and "error" in got["results"][-1]
+    written = sorted(os.listdir(out_dir))
+    assert written == sorted(n.rsplit(".", 1)[0] + ".json" for n in names)
+    assert got["bytes_written"] == sum(os.path.getsize(out_dir / w) for w in written)
+    for n, res in zip(names, got["results"]):
+        text = (out_dir / (n.rsplit(".", 1)[0] + ".json")).read_text()
+        assert text.startswith('{"Residue":[{"serial_number":') and text.endswith("]}")
+        rows = json.loads(text)["Residue"]
+        assert list(rows[0].keys()) == ["serial_number", "insertion_code", "value", "name", "is_polar", "chain_id"]
+        assert len(rows) == len(res)
+        assert [np.float32(r["value"]) for r in rows] == [np.float32(v) for _, v in res]   # the values of the call, bit for bit
+        assert [r["chain_id"] for r in rows] == [c for c, _ in res]
+    # the other levels write their own shapes
+    for level, key in (("atom", "Atom"), ("chain", "Chain"), ("protein", "Protein")):
+        d = tmp_path / level
+        d.mkdir()
+        p = subprocess.run([CLI, "files", level, str(lst), "--out-dir", str(d)], capture_output=True, text=True)
+        assert p.returncode == 0 and sorted(os.listdir(d)) == written
+        assert list(json.loads((d / "1jcd.json").read_text()).keys()) == [key]

@@ -195,3 +195,27 @@ def test_whole_set_with_radii_from_occupancy_meets_the_gate(quality_set, tmp_pat
         pairs += [(sums[c], want[c]) for c in sorted(set(sums) & set(want))]
     rmse = rmse_of(pairs)
     assert len(pairs) >= 160 and rmse <= RMSE_GATE, rmse
+
+
+def test_real_coords_workload_is_the_readers_selection_under_rigid_motions(quality_set):
+    """bench.py's real_coords leg (real_coords.py): the batch is the 87 readable files' selections, whole and in the files'
+    own frame; every tiled copy is a rigid motion of its structure (distances kept to text precision, radii and ids
+    untouched), and no two copies share coordinates."""
+    import real_coords as rc
+    qs = quality_set
+    base = rc.quality_set_batch()
+    assert base.n_structures == 87 and "3sqz" not in base.names
+    (x, y, z, r), ids, _ = select(qs["pdb"](base.names[5]))
+    bx, by, bz, br, bids = base.structure(5)
+    assert np.array_equal(bx, x) and np.array_equal(by, y) and np.array_equal(bz, z) and np.array_equal(br, r) and np.array_equal(bids, ids)
+    t = rc.tiled(base, 2 * base.n_atoms, seed=3)
+    assert t.n_structures == 2 * 87 and t.n_atoms == 2 * base.n_atoms and t.n_residues == 2 * base.n_residues
+    so = t.structure_offsets.astype(np.int64)
+    for s in (0, 33, 86):
+        a = np.stack(t.structure(s)[:3], 1).astype(np.float64)
+        m = np.stack(t.structure(87 + s)[:3], 1).astype(np.float64)
+        assert np.array_equal(a, np.stack(base.structure(s)[:3], 1).astype(np.float64))
+        i, j = np.arange(0, len(a) - 7, 5), np.arange(7, len(a), 5)[: len(np.arange(0, len(a) - 7, 5))]
+        da, dm = np.linalg.norm(a[i] - a[j], axis=1), np.linalg.norm(m[i] - m[j], axis=1)
+        assert np.max(np.abs(da - dm)) < 5e-3 and not np.array_equal(a, m)
+        assert np.array_equal(t.radius[so[s]:so[s + 1]], t.radius[so[87 + s]:so[87 + s + 1]])

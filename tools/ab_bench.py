@@ -25,7 +25,7 @@ def main():
     if args[:1] == ["--rounds"]:
         rounds, args = int(args[1]), args[2:]
     args = args or ["--steps", "10", "--warmup", "2", "--cpu-seconds", "0", "--h2h-steps", "0", "--two-steps", "0",
-                    "--config5-steps", "0", "--files", "0", "--per-call-seconds", "0"]
+                    "--config5-steps", "0", "--files", "0", "--per-call-seconds", "0", "--real-steps", "0", "--hashed-ids-steps", "0"]
     libs = {"base": os.path.join(ROOT, "rustsasa_amd", "lib", "librustsasa_amd.so")}
     for p in sorted(glob.glob(os.path.join(ROOT, "rustsasa_amd", "lib", "variants", "*", "librustsasa_amd.so"))):
         libs[os.path.basename(os.path.dirname(p))] = p

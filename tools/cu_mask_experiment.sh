@@ -5,7 +5,7 @@
 export RSASA_TUNING=1  # (the library reads its RSASA_* measurement switches only then)
 out=gpurun_out/cu_mask.txt
 : > $out
-args="--steps 40 --warmup 5 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --hashed-ids-steps 0"
+args="--steps 40 --warmup 5 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --real-steps 0 --hashed-ids-steps 0"
 run() {  # label, env assignments..., -- bench args
     label=$1; shift
     line=$(env "$@" python3 bench.py $args $EXTRA 2>/dev/null | tail -1)

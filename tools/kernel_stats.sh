@@ -3,7 +3,7 @@
 # average / minimum / maximum duration.  usage (GPU box): tools/kernel_stats.sh [bench.py args]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/kstats; mkdir -p gpurun_out
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 "$@" > gpurun_out/kstats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kstats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --real-steps 0 "$@" > gpurun_out/kstats.log 2>&1
 f=$(find gpurun_out/kstats -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'P'
 import csv, sys

@@ -6,7 +6,7 @@ tag=${1:-occ}; variant=$2
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="--steps 1 --warmup 0 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --hashed-ids-steps 0"
+args="--steps 1 --warmup 0 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --real-steps 0 --hashed-ids-steps 0"
 if [ -n "$variant" ]; then
   code="import sys; sys.path.insert(0, '.'); import rustsasa_amd._capi as c; c.LIB_PATH = 'rustsasa_amd/lib/variants/$variant/librustsasa_amd.so'; import bench; sys.argv = ['bench.py'] + '$args'.split(); bench.main()"
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $out/pmc_o -- python3 -c "$code" > $out/pmc_o.log 2>&1

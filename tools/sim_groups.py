@@ -104,6 +104,41 @@ def one_row_group(st, c, tally, cap):
         tally.add(len(g), u, cap, lookups, 1 if lookups > 1 else 0)
 
 
+def batch_atoms(b):
+    """The batch's cell-sorted atoms as the device lays them out: rows (sid, cx, cy, cz, shift), and the structures' grids."""
+    structs = []
+    for s in range(b.n_structures):
+        x, y, z, r, _ = b.structure(s)
+        structs.append(Struct(x, y, z, r))
+    rows = []
+    for sid, st in enumerate(structs):
+        rows.append(np.concatenate([np.full((st.n, 1), sid), st.c, np.full((st.n, 1), st.shift)], 1))
+    return structs, np.concatenate(rows)
+
+
+def shipped_grouping(b, cap=320, wave=64):
+    """What k_occlusion_mx's grouping does to batch `b` (the shipped rule: a wave owns 64 consecutive atoms, lane 0 starts a
+    group, a union over `cap` slots halves its group): bench.py's real_coords leg prints this beside the kernel's time."""
+    structs, A = batch_atoms(b)
+    N = len(A)
+    sid, cx, cy, cz, sh = A.T
+    bx = cx >> sh
+    st_mask = np.ones(N, bool)
+    st_mask[1:] = (sid[1:] != sid[:-1]) | (cy[1:] != cy[:-1]) | (cz[1:] != cz[:-1]) | (bx[1:] != bx[:-1])
+    natural = int(st_mask.sum())
+    st_mask[::wave] = True
+    t = Tally("shipped")
+    idx = np.flatnonzero(st_mask)
+    for g0, g1 in zip(idx, np.append(idx[1:], N)):
+        one_row_group(structs[sid[g0]], A[g0:g1, 1:4], t, cap)
+    return {"atoms": N, "structures": b.n_structures, "grid_cells_per_atom": round(sum(s.n_cells for s in structs) / N, 2),
+            "atoms_per_natural_group": round(N / natural, 2), "atoms_per_prologue": round(t.atoms / t.groups, 2),
+            "union_slots_per_group": round(t.slots / t.groups, 1), "swept_chunks_per_atom": round(t.chunks / t.atoms, 2),
+            "groups_halved_for_union_overflow": round(t.halved / t.groups, 4), "union_slots": cap,
+            "method": "CPU simulation of the kernel's grouping rule (tools/sim_groups.py; reproduces the 4.79 atoms per prologue "
+                      "that the device stamps counted on the synthetic proteome with 256 slots: 4.71)"}
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     n_s = int(args[0]) if args else 60
@@ -116,15 +151,7 @@ def main():
         order = np.argsort(-sizes, kind="stable")
         # every k-th structure of the size-sorted list: the bench's size mix
         b = bw.select(b, order[:: max(1, len(order) // n_s)][:n_s])
-    structs = []
-    for s in range(b.n_structures):
-        x, y, z, r, _ = b.structure(s)
-        structs.append(Struct(x, y, z, r))
-    # the batch's cell-sorted atoms: (sid, cx, cy, cz, shift)
-    rows = []
-    for sid, st in enumerate(structs):
-        rows.append(np.concatenate([np.full((st.n, 1), sid), st.c, np.full((st.n, 1), st.shift)], 1))
-    A = np.concatenate(rows)
+    structs, A = batch_atoms(b)  # the batch's cell-sorted atoms: (sid, cx, cy, cz, shift)
     N = len(A)
     sid, cx, cy, cz, sh = A.T
     bx = cx >> sh

@@ -3,7 +3,7 @@
 # run with its queue, start and end - where a batch's grid build runs relative to the neighbour's occlusion kernel.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/steps_trace; mkdir -p gpurun_out
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/steps_trace -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --hashed-ids-steps 0 > gpurun_out/steps_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/steps_trace -- python3 bench.py --steps 20 --warmup 3 --cpu-seconds 0 --h2h-steps 0 --two-steps 0 --config5-steps 0 --files 0 --per-call-seconds 0 --real-steps 0 --hashed-ids-steps 0 > gpurun_out/steps_trace.log 2>&1
 python3 - <<'P'
 import csv, glob, re
 kt = glob.glob("gpurun_out/steps_trace/**/*kernel_trace.csv", recursive=True)[0]

@@ -13,5 +13,5 @@ c.LIB_PATH = os.path.join(ROOT, "rustsasa_amd", "lib", "variants", "xcc", "libru
 import bench  # noqa: E402
 
 sys.argv = ["bench.py", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--h2h-steps", "0", "--two-steps", "0",
-            "--config5-steps", "0", "--files", "0"]
+            "--config5-steps", "0", "--files", "0", "--real-steps", "0"]
 bench.main()
