@@ -196,6 +196,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
  * rsasa_host_batch_wait() returns the OLDEST enqueued batch: it blocks until
  * that batch is complete and returns its status (the message is then the
  * context's last error); with nothing enqueued it returns RSASA_OK at once.
+ * Several threads may enqueue and wait on one context at once: a waiting
+ * thread takes the oldest batch no other thread is waiting for already.
  * Every buffer of a batch - inputs and outputs - belongs to the library from
  * the enqueue until the wait that returns the batch.  Pinned (page-locked)
  * host memory makes all copies asynchronous, as for the synchronous call.

@@ -500,6 +500,7 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
         oc.start = ctx->timing ? W.ev[2] : nullptr;
         oc.done = W.ev_occ;
         oc.expect_ids_dropped = ctx->ids_drop_hint;
+        oc.solo = pd.solo_ok && v.ids_check != 0u;
         launch_occlusion(v, lat, ctx->tuning, kOccAll, st, &oc);
     }
     if (overlap) RS_HIP(ctx, hipEventRecord(W.ev_occ, st));
@@ -535,11 +536,25 @@ int wait_one(rsasa_context *ctx, Pending &pd)
             return fail(ctx, RSASA_ERR_INVALID_ARGUMENT,
                         "probe_radius + max radius must be a positive finite number");
         }
+        if (!stt.overflow && ctx->slot[pd.ws].ids_check && (stt.ids_unordered & 2u) != 0u && pd.attempts < 3) {
+            // the batch's one occlusion launch was the id-less instantiation and the ids do matter (OcclusionChain::solo):
+            // nothing was computed - the batch runs again, with its ids and without the check
+            ctx->ids_drop_hint = false;
+            ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
+            pd.ids_needed_known = true;
+            pd.attempts++;
+            int rc = enqueue_batch(ctx, pd, ctx->slot[pd.ws]);
+            if (rc) {
+                pd.active = false;
+                return rc;
+            }
+            continue;
+        }
         if (!stt.overflow) {
             ctx->tuning.deferred_hint = stt.deferred;  // (sizes the next batch's launch over its deferred list)
             if (ctx->slot[pd.ws].ids_check) {
                 ctx->ids_drop_hint = !stt.ids_needed;
-                ctx->ids_unordered_hint = stt.ids_unordered != 0;
+                ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
                 if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             }
             if (ctx->timing) {
@@ -911,6 +926,16 @@ int rsasa_context_ids_dropped(rsasa_context_t *ctx, uint64_t *out_batches)
 int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
                         float probe_radius, size_t n_points, void *hip_stream)
 {
+    return rsasa::batch_enqueue(ctx, batch, probe_radius, n_points, hip_stream, false);
+}
+
+}  // extern "C"
+
+// rsasa_batch_enqueue; ids_needed_known: the caller has looked at the ids itself and found that they matter (the host
+// paths check while the coordinates cross the link): the device does not check again
+int rsasa::batch_enqueue(rsasa_context *ctx, const rsasa_device_batch_t *batch, float probe_radius, size_t n_points, void *hip_stream,
+                         bool ids_needed_known)
+{
     int rc = resolve_ctx(ctx);
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -953,11 +978,15 @@ int rsasa_batch_enqueue(rsasa_context_t *ctx, const rsasa_device_batch_t *batch,
     pd.n_points = n_points;
     pd.stream = hip_stream ? (hipStream_t)hip_stream : (w ? ctx->stream2 : ctx->stream);
     pd.ws = w;
+    pd.solo_ok = true;  // (rsasa_batch_wait runs a batch again when the id-less launch was the wrong guess: wait_one)
+    pd.ids_needed_known = ids_needed_known;
     rc = enqueue_batch(ctx, pd, ctx->slot[w]);
     pd.active = (rc == RSASA_OK);
     if (pd.active) ctx->n_pending++;
     return rc;
 }
+
+extern "C" {
 
 int rsasa_batch_wait(rsasa_context_t *ctx)
 {

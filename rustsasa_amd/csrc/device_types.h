@@ -67,8 +67,9 @@ struct BatchStatus {
     uint64_t grid_cells;      // cells of all grids (statistic)
     uint32_t ids_needed;      // BatchView::ids_check: 0 = the ids of every structure are all different, so "another atom
                               // with my id" never happens - the batch runs as one without ids
-    uint32_t ids_unordered;   // the same: some id does not rise above its predecessor's (k_bounds); k_ids_distinct then looks
-                              // for equal ids structure by structure
+    uint32_t ids_unordered;   // bit 0, the same: some id does not rise above its predecessor's (k_bounds); k_ids_distinct then looks
+                              // for equal ids structure by structure.  Bit 1: the one occlusion launch of the batch was the id-less
+                              // instantiation and the ids turned out to matter (OcclusionChain::solo): nothing was computed
 };
 static_assert(sizeof(BatchStatus) == 56, "BatchStatus layout");
 
@@ -195,9 +196,14 @@ enum OcclusionPart : uint32_t {
 // nullable) there and `done` behind it.  With BatchView::ids_check the host does not know which instantiation will work:
 // `expect_ids_dropped` (what the context's last batch did) puts the other one FIRST, in front of the wait, where it runs
 // beside the neighbour's kernel for nothing; a wrong guess only loses the ordering for that batch.
+// `solo` (callers that can run a batch again: rsasa_batch_wait): when the ids are expected to be dropped only the id-less
+// instantiation is launched; should the device find that the ids do matter, that launch does nothing but raise bit 1 of
+// BatchStatus::ids_unordered, and the caller runs the batch again with its ids (once, at a change of the id pattern -
+// against an empty launch of 45 000 workgroups in front of every batch's working kernel: 15 us of every step).
 struct OcclusionChain {
     hipEvent_t wait = nullptr, start = nullptr, done = nullptr;
     bool expect_ids_dropped = true;
+    bool solo = false;
 };
 void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTuning &tune,
                       OcclusionPart part, hipStream_t stream, const OcclusionChain *chain = nullptr);

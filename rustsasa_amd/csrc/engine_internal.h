@@ -71,6 +71,7 @@ struct Pending {
     const float *radius_table = nullptr;  // (BatchView::radius8); batch.radius is then not read
     int ws = 0;                      // the workspace (and host slot) the batch runs in
     bool ids_needed_known = false;   // the host has checked the ids itself and found that they matter (BatchView::ids_check off)
+    bool solo_ok = false;            // the caller runs the batch again if asked to (rsasa_batch_wait: OcclusionChain::solo)
 };
 
 // The distinct radii of a host batch, collected while worker threads turn the radii into one-byte codes: a
@@ -266,6 +267,7 @@ struct HostStream {
         int rc = 0;
         std::string error;
         bool taken = false, done = false;
+        bool waited_for = false;  // a caller's thread is in rsasa_host_batch_wait for this batch
     };
     static constexpr int kMaxWorkers = 4;
     int n_workers = 2;
@@ -495,6 +497,8 @@ int wait_oldest(rsasa_context *ctx);
 int wait_pending(rsasa_context *ctx);
 int resolve_ctx(rsasa_context *&ctx);
 int context_create(int device, int own_queues, rsasa_context_t **out_ctx);  // own_queues: rsasa_context::own_queues
+int batch_enqueue(rsasa_context *ctx, const rsasa_device_batch_t *batch, float probe_radius, size_t n_points, void *hip_stream,
+                  bool ids_needed_known);  // rsasa_batch_enqueue with the host's verdict on the ids
 
 // ---- the small-batch path (host_batch.cpp), shared with the call combiner (combine.cpp) ----
 // Where a small batch's atoms come from: columns (the SoA entry points) or rsasa_atom_t records (rsasa_calculate_sasa_internal:

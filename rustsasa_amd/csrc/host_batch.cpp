@@ -643,7 +643,8 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
         bt.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
         bt.out_neighbor_counts = nullptr;
         if (!(na || nr)) return RSASA_OK;
-        return rsasa_batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr);
+        // (a verdict of the host's own check goes along: the device does not look at the ids again)
+        return batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr, host_check && id && !drop_ids[c]);
     };
     // staged results of output slot k that still have to be moved to the caller's arrays
     struct Staged { bool active = false; size_t a0 = 0, na = 0, r0 = 0, nr = 0; } staged[kSlots];
@@ -737,7 +738,7 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
             else ctx->tuning.deferred_hint = stt.deferred;
             if (!stt.overflow && ctx->slot[k].ids_check) {
                 ctx->ids_drop_hint = !stt.ids_needed;
-                ctx->ids_unordered_hint = stt.ids_unordered != 0;
+                ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
                 if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             }
         };
@@ -959,8 +960,10 @@ int rsasa_host_batch_enqueue(rsasa_context_t *ctx, const float *x, const float *
     return RSASA_OK;
 }
 
-int rsasa_host_batch_wait(rsasa_context_t *ctx)
+// rsasa_host_batch_wait; *took: a batch was there for this thread to wait for
+static int host_batch_wait(rsasa_context_t *ctx, bool *took)
 {
+    *took = false;
     int rc = resolve_ctx(ctx);
     if (rc) return rc;
     HostStream *hs = nullptr;
@@ -972,30 +975,37 @@ int rsasa_host_batch_wait(rsasa_context_t *ctx)
     std::shared_ptr<HostStream::Job> job;
     {
         std::unique_lock<std::mutex> lk(hs->mu);
-        if (hs->jobs.empty()) return RSASA_OK;
-        job = hs->jobs.front();
+        // the oldest batch that no other thread is waiting for already (two threads of the caller may wait at once: each
+        // takes a batch of its own - both taking the front one and both removing "it" removed a batch nobody had waited
+        // for, or one from an empty queue: found by tests/test_gpu_concurrency.py test_host_stream_under_stress)
+        for (auto &j : hs->jobs)
+            if (!j->waited_for) { job = j; break; }
+        if (!job) return RSASA_OK;
+        job->waited_for = true;
+        *took = true;
         hs->cv_done.wait(lk, [&] { return job->done; });
-        hs->jobs.pop_front();
+        for (auto it = hs->jobs.begin(); it != hs->jobs.end(); ++it)
+            if (*it == job) { hs->jobs.erase(it); break; }
     }
     hs->cv_done.notify_all();  // (an enqueue may be waiting for room)
     if (job->rc) return fail(ctx, job->rc, job->error.c_str());
     return RSASA_OK;
 }
 
+int rsasa_host_batch_wait(rsasa_context_t *ctx)
+{
+    bool took;
+    return host_batch_wait(ctx, &took);
+}
+
 int rsasa_host_batch_wait_all(rsasa_context_t *ctx)
 {
     int first = RSASA_OK;
     for (;;) {
-        {
-            int rc = resolve_ctx(ctx);
-            if (rc) return rc;
-            std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-            if (!ctx->host_stream) return first;
-            std::lock_guard<std::mutex> lk2(ctx->host_stream->mu);
-            if (ctx->host_stream->jobs.empty()) return first;
-        }
-        const int rc = rsasa_host_batch_wait(ctx);
+        bool took;
+        const int rc = host_batch_wait(ctx, &took);
         if (rc && !first) first = rc;
+        if (!took) return first;  // (what is still queued, another thread of the caller is waiting for)
     }
 }
 

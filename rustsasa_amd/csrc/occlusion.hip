@@ -130,11 +130,19 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
         // one that BatchStatus::ids_needed does not ask for returns at once (its workgroups touch nothing, the claim
         // counters included).  The one the host expects to return goes first, in front of the chain's wait.
         const bool dropped = !chain || chain->expect_ids_dropped;
-        if (dropped) launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
-        else launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
-        chain_begin(chain, stream);
-        if (dropped) launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
-        else launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        if (chain && chain->solo && dropped) {
+            // (the caller runs the batch again if the guess was wrong: OcclusionChain::solo)
+            OccArgs3 only = a3;
+            only.ids_check = 2u;
+            chain_begin(chain, stream);
+            launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, only);
+        } else {
+            if (dropped) launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+            else launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+            chain_begin(chain, stream);
+            if (dropped) launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+            else launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        }
     } else {
         chain_begin(chain, stream);
         if (has_id) launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);

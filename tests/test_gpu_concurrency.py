@@ -368,3 +368,140 @@ def test_ninth_host_batch_is_refused_at_once():
         ctx.host_batch_wait_all()
         for o in outs:
             assert np.array_equal(o, want)
+
+
+def test_host_stream_under_stress():
+    """The stream of host batches (HostStream / LinkGate / LinkTurn / FoldPool behind rsasa_host_batch_enqueue) with two
+    caller threads on ONE context: 2 000 batches - single structures, small batches, 160 k-atom batches and one that is
+    cut into sub-batches - enqueued, waited for one by one, waited for all at once and mixed with synchronous batch and
+    per-structure calls, in an order drawn at random; every tenth batch is one the engine must refuse (an infinite
+    coordinate), wherever it falls in the queue; a full queue is the caller's to drain.  Every batch's values against the
+    oracle, every refused batch reported exactly once, nothing hangs; then a context is destroyed with batches still
+    queued (they finish first), and the device's memory is back where it was."""
+    import random
+    import time
+    import torch
+    import rustsasa_amd
+    from rustsasa_amd._capi import ptr
+    torch.cuda.synchronize()
+    with rustsasa_amd.Context(0) as warm:  # (the runtime's own start-up allocations are not this test's)
+        warm.calculate_sasa_soa(*_cases()[0][:5], PROBE, 100)
+    free0 = torch.cuda.mem_get_info()[0]
+    pool = []
+    for n, seed in ((1, 21), (1, 22), (3, 23), (6, 24), (60, 25), (1300, 26)):
+        b = bw.synthetic_proteome(n, seed=seed)
+        want = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100, 8, threads=0)
+        pool.append((b, want, po.residue_sums(want, b.residue_offsets)))
+    assert pool[-1][0].n_atoms > 3_000_000  # (large enough to be cut into sub-batches)
+    bad = bw.synthetic_proteome(2, seed=27)
+    bad_x = bad.x.copy()
+    bad_x[5] = np.inf
+    weights = [30, 30, 20, 12, 7, 1]
+    records, lock = [], threading.Lock()
+    errors, refused_seen, refused_sent = [], [0], [0]
+    ctx = rustsasa_amd.Context(0)
+    lib, h = ctx._lib, ctx._h
+    N_BATCHES = 2000
+    sent = [0]
+
+    def enqueue(rng):
+        with lock:
+            if sent[0] >= N_BATCHES:
+                return False
+            sent[0] += 1
+            k = sent[0]
+        if k % 10 == 0:
+            b, x = bad, bad_x
+            rec = None
+        else:
+            b, want, want_res = pool[rng.choices(range(len(pool)), weights)[0]]
+            x = b.x
+            rec = (np.full(b.n_atoms, np.nan, np.float32), np.full(b.n_residues, np.nan, np.float32), want, want_res)
+        out_a = rec[0] if rec else np.empty(b.n_atoms, np.float32)
+        out_r = rec[1] if rec else np.empty(b.n_residues, np.float32)
+        for _ in range(10000):
+            rc = lib.rsasa_host_batch_enqueue(h, ptr(x), ptr(b.y), ptr(b.z), ptr(b.radius), ptr(b.ids), ptr(b.structure_offsets),
+                                              b.n_structures, PROBE, 100, ptr(out_a), ptr(b.residue_offsets), b.n_residues, ptr(out_r))
+            if rc != -7:
+                break
+            wait_one()  # (queue full: somebody has to take a batch out)
+        if rc != 0:
+            errors.append(("enqueue", k, rc))
+            return True
+        with lock:
+            records.append(rec if rec else (out_a, out_r, x, None))  # (all arrays stay alive until the end)
+            if rec is None:
+                refused_sent[0] += 1
+        return True
+
+    def wait_one():
+        rc = lib.rsasa_host_batch_wait(h)
+        if rc == -5:
+            with lock:
+                refused_seen[0] += 1
+        elif rc != 0:
+            errors.append(("wait", rc))
+
+    def work(tid):
+        rng = random.Random(100 + tid)
+        try:
+            more = True
+            while more:
+                op = rng.random()
+                if op < 0.55:
+                    more = enqueue(rng)
+                elif op < 0.80:
+                    wait_one()
+                elif op < 0.84:
+                    while True:  # rsasa_host_batch_wait_all returns the FIRST error: count every refused batch through single waits
+                        with lock:
+                            pending = len(records) - done_count()
+                        if pending <= 0:
+                            break
+                        wait_one()
+                elif op < 0.92:
+                    b, want, _ = pool[rng.choice((0, 1, 2, 3))]
+                    got, _ = ctx.calculate_sasa_batch(b.x, b.y, b.z, b.radius, b.ids, b.structure_offsets, PROBE, 100)
+                    if not np.array_equal(got, want):
+                        errors.append(("sync batch", tid))
+                else:
+                    b, want, _ = pool[rng.choice((0, 1))]
+                    if not np.array_equal(ctx.calculate_sasa_soa(b.x, b.y, b.z, b.radius, b.ids, PROBE, 100), want):
+                        errors.append(("per-structure call", tid))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    def done_count():
+        return sum(1 for r in records if r[3] is None or not np.isnan(r[0][-1]))
+
+    t0 = time.time()
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "the stream of host batches hangs"
+    for _ in range(len(records) + 8):  # whatever is still queued (a wait with nothing queued returns at once)
+        wait_one()
+    assert errors == [], errors[:5]
+    assert sent[0] == N_BATCHES and refused_sent[0] == N_BATCHES // 10 == refused_seen[0]
+    n_ok = 0
+    for out_a, out_r, want, want_res in records:
+        if want_res is None:
+            continue
+        assert np.array_equal(out_a, want) and np.array_equal(out_r, want_res)
+        n_ok += 1
+    assert n_ok == N_BATCHES - N_BATCHES // 10
+    # destroyed with batches still queued: they finish, their results are complete
+    b, want, want_res = pool[4]
+    outs = [(np.full(b.n_atoms, np.nan, np.float32), np.full(b.n_residues, np.nan, np.float32)) for _ in range(5)]
+    for a, r in outs:
+        assert lib.rsasa_host_batch_enqueue(h, ptr(b.x), ptr(b.y), ptr(b.z), ptr(b.radius), ptr(b.ids), ptr(b.structure_offsets),
+                                            b.n_structures, PROBE, 100, ptr(a), ptr(b.residue_offsets), b.n_residues, ptr(r)) == 0
+    ctx.close()
+    for a, r in outs:
+        assert np.array_equal(a, want) and np.array_equal(r, want_res)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - free0) < 96 * 2 ** 20, f"device memory {free0 >> 20} -> {free1 >> 20} MB"
+    print(f"stress: {N_BATCHES} host batches from two threads in {time.time() - t0:.1f} s")
