@@ -151,14 +151,9 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
     chain_end(chain, stream);
 }
 
-// Waves per workgroup of k_occlusion_mx with at most 128 points.  4: the waves share an LDS copy of the point tables.
-// 1 (measured in round 5, kept as a build option): single-wave workgroups that read the tables from global memory
-// (Lattice::mx_tab) - a wave's LDS is free the moment it ends, wave-slot utilisation 90 -> 94 % (SQ_WAVE_CYCLES), but every
-// wave waits longer for its operands and the kernel's time is the same (3.497 against 3.473 ms): the kernel is bound by
-// its units, not by the waves in flight.
-#ifndef MX_NW
-#define MX_NW 4
-#endif
+// (Waves per workgroup of k_occlusion_mx with at most 128 points: 4, sharing an LDS copy of the point tables.  Single-wave
+// workgroups that read the tables from global memory - a wave's LDS is free the moment it ends, wave-slot utilisation
+// 90 -> 94 % - measured the same time, 3.497 against 3.473 ms: DESIGN.md 7, tools/experiments/round6_removed_switches.patch.)
 constexpr uint32_t kMxLdsBudget = 157u * 1024u;  // what workgroups of k_occlusion_mx can share of a CU's 160 KB (see launch_occlusion)
 
 // static LDS of the many-point instantiations per wave (the same for every NW: the lists are per wave).  Contexts on
@@ -257,9 +252,8 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
             // dynamic LDS: the points as f32 (16 B each) and f16 (8 B each) matrix operands
             const bool has_id = b.id != nullptr;
             // (+ 16 zero entries of the f32 table: the column that pads phase B's last round)
-            // (-DMX_NW=1: single-wave workgroups, the tables read from Lattice::mx_tab, no dynamic LDS)
-            constexpr int kNW = MX_NW;
-            constexpr uint32_t kTabs = kNW == 1 ? 0u : 1u;
+            constexpr int kNW = 4;
+            constexpr uint32_t kTabs = 1u;
             if (lat.n_points <= 96u) launch_mx<6, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 96u + 256u), stream, a3, chain);
             else if (lat.n_points <= 112u) launch_mx<7, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 112u + 256u), stream, a3, chain);
             else if (lat.n_points <= 128u) launch_mx<8, false, kNW>(has_id, rem, b.n_atoms, kTabs * (24u * 128u + 256u), stream, a3, chain);
@@ -278,9 +272,6 @@ void launch_occlusion(const BatchView &b, const Lattice &lat, const OcclusionTun
                     const uint32_t waves = min(nw * (kMxLdsBudget / total), nw >= 8u ? 24u : 28u);  // (72 / 80 registers: 7 / 6 waves per SIMD)
                     if (waves > best_waves) { best_nw = nw; best_waves = waves; }
                 }
-#ifdef MX_FORCE_NW  // experiments only
-                best_nw = MX_FORCE_NW;
-#endif
                 if (best_nw == 4u) launch_mx<8, true, 4>(has_id, rem, b.n_atoms, dyn, stream, a3, chain);
                 else if (best_nw == 8u) launch_mx<8, true, 8>(has_id, rem, b.n_atoms, dyn, stream, a3, chain);
                 else launch_mx<8, true, 12>(has_id, rem, b.n_atoms, dyn, stream, a3, chain);

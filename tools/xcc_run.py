@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One bench step on the -DMX_DEBUG_XCC build of the library (make OUT=../lib/variants/xcc/... EXTRA="-DMX_PERSIST_ALL=1
--DMX_DEBUG_XCC"): k_occlusion_mx prints the XCD (HW_REG_XCC_ID) a few of its workgroups run on.  On the GPU box:
+"""One bench step on the -DMX_DEBUG_XCC build of the library (make OUT=../lib/variants/xcc/... EXTRA=-DMX_DEBUG_XCC):
+k_occlusion_mx prints the XCD (HW_REG_XCC_ID) a few of its workgroups run on.  On the GPU box:
     python tools/xcc_run.py 2>&1 | grep MXXCC"""
 import os
 import sys
