@@ -302,6 +302,659 @@ int run_small_host_batch(rsasa_context *ctx, const SmallSource &in, const uint32
 extern "C" {
 
 
+}  // extern "C"
+
+namespace {
+
+// RSASA_H2H_TRACE=1 (under RSASA_TUNING=1): the host-side phases of a pipelined call and, from HIP events, every sub-batch's
+// uploads and kernels, on one clock for all contexts of the process (tools/h2h_stream_trace.py).  Measurement only.
+struct H2HTrace {
+    static bool on()
+    {
+        static const bool v = tuning_env("RSASA_H2H_TRACE") != nullptr;
+        return v;
+    }
+    static std::chrono::steady_clock::time_point epoch()
+    {
+        static const auto e = std::chrono::steady_clock::now();
+        return e;
+    }
+    struct Ref {
+        std::mutex mu;
+        hipEvent_t ev = nullptr;  // ties the device's clock to the host's
+        double host_us = 0;
+    };
+    static Ref &ref()
+    {
+        static Ref r;
+        return r;
+    }
+    rsasa_context *ctx;
+    std::chrono::steady_clock::time_point t0;
+    explicit H2HTrace(rsasa_context *c) : ctx(c), t0(std::chrono::steady_clock::now())
+    {
+        (void)epoch();
+        if (!on()) return;
+        Ref &r = ref();
+        std::lock_guard<std::mutex> lk(r.mu);
+        if (!r.ev && hipEventCreate(&r.ev) == hipSuccess) {
+            (void)hipEventRecord(r.ev, ctx->stream);
+            (void)hipEventSynchronize(r.ev);
+            r.host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch()).count();
+        }
+        for (auto &row : ctx->tr_ev)
+            for (hipEvent_t &e : row)
+                if (!e) (void)hipEventCreate(&e);
+    }
+    void rec(int k, int i, hipStream_t s) const
+    {
+        if (on() && ctx->tr_ev[k][i]) (void)hipEventRecord(ctx->tr_ev[k][i], s);
+    }
+    void say(const char *what) const
+    {
+        if (!on()) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "h2h ctx %p at %9.1f us, %8.1f us into the call: %s\n", (void *)ctx,
+                     std::chrono::duration<double, std::micro>(now - epoch()).count(),
+                     std::chrono::duration<double, std::micro>(now - t0).count(), what);
+    }
+    void device_side(size_t n_sub) const  // each sub-batch's uploads and kernels on the host trace's clock
+    {
+        Ref &r = ref();
+        if (!on() || !r.ev || n_sub > (size_t)rsasa_context::kSlots) return;
+        for (size_t c = 0; c < n_sub; c++) {
+            float t[4] = {};
+            for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&t[i], r.ev, ctx->tr_ev[c][i]);
+            std::fprintf(stderr, "h2h ctx %p device: sub-batch %zu uploads %9.1f .. %9.1f us, kernels %9.1f .. %9.1f us\n", (void *)ctx, c,
+                         r.host_us + t[0] * 1e3, r.host_us + t[1] * 1e3, r.host_us + t[2] * 1e3, r.host_us + t[3] * 1e3);
+        }
+    }
+};
+
+// ONE coding pool per device for all its contexts: two contexts with a stream of host batches between them (or
+// process_files' pair) would otherwise run two pools of sixteen threads against each other - under a CPU quota (the
+// measurement boxes: 16 CPUs) both are throttled, a sub-batch's coding takes 8 ms instead of 1 and its upload waits for
+// it.  Jobs are worked off in the order they were submitted, whoever submitted them.
+FoldPool *device_fold_pool(rsasa_context *ctx)
+{
+    static std::mutex pools_mu;
+    static FoldPool *pools[64] = {};
+    unsigned nt = std::thread::hardware_concurrency() / 4;
+    if (const char *v = tuning_env("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
+    std::lock_guard<std::mutex> lkp(pools_mu);
+    const int d = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+    if (!pools[d]) pools[d] = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)), ctx->node);  // (lives as long as the process)
+    return pools[d];
+}
+
+bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t at{};
+    if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// One rsasa_calculate_sasa_batch call on the general path (whatever the small path does not take), in four steps:
+//   plan()     the cut into sub-batches of whole structures and residues
+//   stage()    device buffers, pinned blocks, what the host prepares per sub-batch (id folds, radius codes) and how results leave
+//   run_one()  a batch that is one sub-batch: upload, kernels, wait, copy out
+//   run_piped() several sub-batches on three streams: copy-in (c + 1), compute (c), copy-out (c - 1)
+// The context is locked and its device current for the object's lifetime.
+struct HostBatch {
+    static constexpr int kSlots = rsasa_context::kSlots;
+    static constexpr size_t kTableWords = 256;  // a sub-batch's offsets block on the device: radius table | residue offsets
+    // the call
+    rsasa_context *ctx;
+    const float *x, *y, *z, *radius;
+    const uint64_t *id;
+    const uint32_t *structure_offsets;
+    size_t n_structures;
+    float probe_radius;
+    size_t n_points;
+    float *out_atom_sasa;
+    const uint32_t *residue_offsets;
+    size_t n_residues;
+    float *out_residue_sasa;
+    size_t N = 0;
+    bool want_res = false;
+    H2HTrace tr;
+    // plan
+    std::vector<size_t> cut{0};  // structure indices where sub-batches begin / end
+    std::vector<size_t> res_cut;
+    size_t max_atoms = 1, max_res = 1, n_sub = 1;
+    bool piped = false;
+    int n_slots = 1;
+    // stage
+    DeviceBuffer *bx[kSlots], *by[kSlots], *bz[kSlots], *br[kSlots], *bi[kSlots], *bo[kSlots], *oa[kSlots], *orr[kSlots];
+    const float *dev_x[kSlots] = {}, *dev_y[kSlots] = {}, *dev_z[kSlots] = {};
+    const uint64_t *id_mapped = nullptr;
+    bool fold_ids = false, code_radii = false, check_ids = false, host_check = false;
+    struct Pack { size_t base = 0, o_res = 0, o_id = 0, o_r8 = 0, bytes = 0; };  // a sub-batch's pinned block: radius table |
+    std::vector<Pack> pack;                                                      // residue offsets | radius codes | folded ids
+    std::vector<unsigned long long> fold_job;
+    bool atoms_direct = true, res_direct = true;
+    size_t stage_atoms = 0, stage_bytes = 0;
+    std::vector<uint32_t> so[kSlots];  // host copies of the rebased offsets stay alive until their sub-batch has been waited for
+    std::vector<char> use_codes;       // sub-batch c's radii travel as codes (decided once its coding job is done)
+    std::vector<char> drop_ids;        // sub-batch c's ids stay on the host: those of each of its structures increase strictly, so
+                                       // they are all different and change nothing (IdOrder; found by the workers that fold them)
+    std::unique_ptr<std::atomic<int>[]> ids_matter;
+    struct Staged { bool active = false; size_t a0 = 0, na = 0, r0 = 0, nr = 0; } staged[kSlots];  // results of output slot k that
+                                                                                                   // still have to be moved to the caller's arrays
+    // No coding job may outlive the call: the workers read the caller's arrays and write the flags above.  (The LAST member:
+    // destroyed first, so it waits while everything a job touches is still there - as a local of the old one-function form
+    // it was destroyed after the flags, which only an error return with jobs still running could have noticed.)
+    struct FoldDrain {
+        FoldPool *pool = nullptr;
+        unsigned long long last = 0;
+        ~FoldDrain() { if (pool) pool->wait(last); }
+    } fold_drain;
+    HostBatch(rsasa_context *c, const float *x_, const float *y_, const float *z_, const float *r_, const uint64_t *id_, const uint32_t *so_,
+              size_t ns, float probe, size_t np, float *oa_, const uint32_t *ro_, size_t nr, float *or_)
+        : ctx(c), x(x_), y(y_), z(z_), radius(r_), id(id_), structure_offsets(so_), n_structures(ns), probe_radius(probe), n_points(np),
+          out_atom_sasa(oa_), residue_offsets(ro_), n_residues(nr), out_residue_sasa(or_), tr(c)
+    {
+        N = n_structures ? structure_offsets[n_structures] : 0;
+        want_res = residue_offsets && n_residues;
+    }
+
+    size_t atoms_of(size_t c) const { return structure_offsets[cut[c + 1]] - structure_offsets[cut[c]]; }
+    size_t residues_of(size_t c) const { return want_res ? res_cut[c + 1] - res_cut[c] : 0; }
+
+    // Large batches are cut into sub-batches of whole structures (and whole residues) whose host-to-device copies run on
+    // a second stream into a second set of input buffers while the previous sub-batch computes: the PCIe transfer hides
+    // behind the kernels.
+    void plan()
+    {
+        size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
+        if (const char *v = tuning_env("RSASA_SUB_ATOMS")) kSubAtoms = (size_t)std::max(100000, std::atoi(v));
+        if (N >= 2 * kSubAtoms && n_structures > 1) {
+            // (a worker of a stream of host batches: the NEXT call's uploads hide a call's fill and drain, so two sub-batches
+            // - one upload running beside one half's kernels - are enough, and every sub-batch fewer is a grid build fewer
+            // between the occlusion kernels: HostStream)
+            size_t max_sub = ctx->stream_sub_batches ? ctx->stream_sub_batches : 8;
+            if (const char *v = tuning_env("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
+            const size_t want = std::min<size_t>(max_sub, N / kSubAtoms);
+            // The link is the longest leg.  The first sub-batch's upload is not hidden behind anything, and nothing hides
+            // the last one's kernels: each gets half a share (RSASA_H2H_TAIL=0: only the first).
+            static const bool half_tail = !(tuning_env("RSASA_H2H_TAIL") && std::atoi(tuning_env("RSASA_H2H_TAIL")) == 0);
+            const size_t first = half_tail ? N / (2 * want - 2) : N / (2 * want - 1);
+            const size_t share = half_tail ? 2 * first : (N - first) / (want - 1);
+            auto boundary = [&](size_t k) { return first + (k - 1) * share; };  // first atom of sub-batch k >= 1
+            size_t next = 1;
+            for (size_t sidx = 1; sidx < n_structures && next < want; sidx++) {
+                const size_t a0 = structure_offsets[sidx];
+                if (a0 < boundary(next)) continue;
+                if (want_res && !std::binary_search(residue_offsets, residue_offsets + n_residues + 1, (uint32_t)a0))
+                    continue;  // a residue spans this structure boundary: cut later
+                cut.push_back(sidx);
+                while (next < want && boundary(next) <= a0) next++;
+            }
+        }
+        cut.push_back(n_structures);
+        res_cut.assign(cut.size(), 0);
+        for (size_t c = 0; c + 1 < cut.size(); c++) {
+            max_atoms = std::max<size_t>(max_atoms, atoms_of(c));
+            if (want_res) {
+                res_cut[c + 1] = c + 2 == cut.size()
+                                     ? n_residues
+                                     : (size_t)(std::lower_bound(residue_offsets, residue_offsets + n_residues + 1,
+                                                                 structure_offsets[cut[c + 1]]) - residue_offsets);
+                max_res = std::max(max_res, res_cut[c + 1] - res_cut[c]);
+            }
+        }
+        piped = cut.size() > 2;
+        n_sub = cut.size() - 1;
+        n_slots = piped ? (int)std::min<size_t>((size_t)kSlots, n_sub) : 1;
+    }
+
+    int stage()
+    {
+        int rc;
+        if ((rc = stage_device_buffers())) return rc;
+        if ((rc = stage_host_preparation())) return rc;
+        if ((rc = stage_outputs())) return rc;
+        tr.say("setup done");
+        use_codes.assign(cut.size(), 0);
+        drop_ids.assign(cut.size(), 0);
+        ids_matter.reset(new (std::nothrow) std::atomic<int>[cut.size()]);
+        if (!ids_matter) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "id flags");
+        return RSASA_OK;
+    }
+
+    int stage_device_buffers()
+    {
+        int rc;
+        bx[0] = &ctx->in_x; by[0] = &ctx->in_y; bz[0] = &ctx->in_z; br[0] = &ctx->in_r;
+        bi[0] = &ctx->in_id; bo[0] = &ctx->in_res; oa[0] = &ctx->atom_sasa; orr[0] = &ctx->out_res;
+        for (int k = 1; k < kSlots; k++) {
+            rsasa_context::MoreSlot &m = ctx->more[k - 1];
+            bx[k] = &m.x; by[k] = &m.y; bz[k] = &m.z; br[k] = &m.r; bi[k] = &m.id; bo[k] = &m.res; oa[k] = &m.atom_sasa; orr[k] = &m.out_res;
+        }
+        for (int k = 0; k < n_slots; k++) {
+            if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
+            if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
+            if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
+            dev_x[k] = (const float *)bx[k]->p; dev_y[k] = (const float *)by[k]->p; dev_z[k] = (const float *)bz[k]->p;
+            if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
+            if (id && !piped && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;  // (pipelined: stage_host_preparation, unless the ids are folded)
+            if (want_res && !piped && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
+            if ((rc = reserve(ctx, *oa[k], max_atoms * 4))) return rc;
+            if (want_res && (rc = reserve(ctx, *orr[k], max_res * 4))) return rc;
+        }
+        return RSASA_OK;
+    }
+
+    // What the host prepares for a sub-batch, and the pinned blocks it travels in.
+    int stage_host_preparation()
+    {
+        int rc;
+        // Ids on the pipelined path: the link is the longest leg, and the matrix-core kernel only looks at 32-bit folds
+        // of the ids.  With the caller's ids in pinned memory the host folds them (a few worker threads, one sub-batch
+        // ahead of the uploads) and 4 bytes per atom cross the link instead of 8; the general kernel reads the few full
+        // ids it needs (atoms whose folds collide) straight from the caller's array, mapped into the device's
+        // address space.  Pageable ids, or a sub-batch the per-atom kernels take: the 64-bit ids are uploaded.
+        if (piped && id && !tuning_env("RSASA_NO_ID_FOLD")) {
+            Lattice lat_probe;
+            void *dp = nullptr;
+            if (n_points >= 1 && n_points <= (1u << 24) && get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
+                hipHostGetDevicePointer(&dp, const_cast<uint64_t *>(id), 0) == hipSuccess && dp) {
+                fold_ids = true;
+                for (size_t c = 0; c + 1 < cut.size(); c++) fold_ids &= occlusion_uses_mx(ctx->tuning, lat_probe, (uint32_t)atoms_of(c));
+                id_mapped = (const uint64_t *)dp;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        // Radii on the pipelined path: one-byte codes into the table of the batch's distinct radii (RadiusCodec), coded by
+        // the same worker threads.
+        code_radii = piped && !tuning_env("RSASA_NO_RADIUS_CODES");
+        // the sub-batches' pinned blocks: radius table | residue offsets | radius codes | folded ids, 16-byte aligned parts
+        pack.assign(cut.size(), Pack());
+        if (piped) {
+            auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+            size_t total = 0, largest = 0;
+            for (size_t c = 0; c + 1 < cut.size(); c++) {
+                const size_t na = atoms_of(c), nr = residues_of(c);
+                Pack &pk = pack[c];
+                pk.base = total;
+                pk.o_res = kTableWords * 4;
+                // (the folded ids last: a sub-batch whose ids turn out not to matter is uploaded without them)
+                pk.o_r8 = pk.o_res + up16(want_res ? (nr + 1) * 4 : 0);
+                pk.o_id = pk.o_r8 + up16(code_radii ? na : 0);
+                pk.bytes = pk.o_id + up16(fold_ids ? na * 4 : 0);
+                total += pk.bytes;
+                largest = std::max(largest, pk.bytes);
+            }
+            for (int k = 0; k < n_slots; k++)
+                if ((rc = reserve(ctx, ctx->in_pack[k], largest))) return rc;
+            if (total > ctx->h_pack_cap) {
+                if (ctx->h_pack) {
+                    RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+                    RS_HIP(ctx, hipHostFree(ctx->h_pack));
+                    ctx->h_pack = nullptr;
+                    ctx->h_pack_cap = 0;
+                }
+                const size_t cap = total + total / 4;
+                RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_pack, cap, hipHostMallocDefault));
+                ctx->h_pack_cap = cap;
+            }
+        }
+        // Ids that are all different within their structure change nothing (BatchView::ids_check).  The pipelined path's
+        // coding workers look while they fold; one large sub-batch is checked by the same workers while its coordinates
+        // cross the link (then its 8 bytes of id per atom stay on the host); anything smaller is checked on the device.
+        check_ids = id && !tuning_env("RSASA_NO_ID_CHECK");
+        if (!piped && check_ids && cut.size() == 2 && structure_offsets[n_structures] >= 262144u && n_points >= 1 && n_points <= (1u << 24)) {
+            Lattice lat_probe;
+            host_check = get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
+                         occlusion_uses_mx(ctx->tuning, lat_probe, structure_offsets[n_structures]);
+        }
+        if ((fold_ids || code_radii || host_check) && !ctx->fold_pool) {
+            ctx->fold_pool = device_fold_pool(ctx);
+            if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
+        }
+        fold_job.assign(cut.size(), 0);
+        for (int k = 0; k < n_slots && want_res && !piped; k++) {
+            rsasa_context::HostSlot &hs = ctx->slot[k];
+            if (max_res + 1 <= hs.h_res_cap) continue;
+            if (hs.h_res) {
+                RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+                RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                RS_HIP(ctx, hipHostFree(hs.h_res));
+                hs.h_res = nullptr;
+                hs.h_res_cap = 0;
+            }
+            const size_t cap = max_res + 1 + max_res / 4;
+            RS_HIP(ctx, hipHostMalloc((void **)&hs.h_res, cap * sizeof(uint32_t), hipHostMallocDefault));
+            hs.h_res_cap = cap;
+        }
+        for (int k = 0; k < n_slots && piped && id && !fold_ids; k++)
+            if ((rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
+        return RSASA_OK;
+    }
+
+    // Results leave on their own stream while the next sub-batch computes.  A destination in pinned (page-locked) host
+    // memory takes the copy directly; a pageable one gets it through pinned staging, moved to its place by this thread
+    // once the copy has landed.
+    int stage_outputs()
+    {
+        atoms_direct = !out_atom_sasa || is_pinned(out_atom_sasa);
+        res_direct = !want_res || is_pinned(out_residue_sasa);
+        stage_atoms = (out_atom_sasa && !atoms_direct) ? max_atoms * 4 : 0;
+        stage_bytes = stage_atoms + ((want_res && !res_direct) ? max_res * 4 : 0);
+        for (int k = 0; k < n_slots && stage_bytes; k++) {
+            if (stage_bytes <= ctx->h_out_cap[k]) continue;
+            if (ctx->h_out[k]) {
+                RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
+                RS_HIP(ctx, hipHostFree(ctx->h_out[k]));
+                ctx->h_out[k] = nullptr;
+                ctx->h_out_cap[k] = 0;
+            }
+            RS_HIP(ctx, hipHostMalloc(&ctx->h_out[k], stage_bytes + stage_bytes / 4, hipHostMallocDefault));
+            ctx->h_out_cap[k] = stage_bytes + stage_bytes / 4;
+        }
+        return RSASA_OK;
+    }
+
+    // the coordinates of a sub-batch do not wait for its coding job (ids, radius codes): they are queued first, and the
+    // first sub-batch's start crossing the link while its block is still being written
+    int upload_xyz(size_t c, hipStream_t st)
+    {
+        const int k = (int)(c % kSlots);
+        const size_t a0 = structure_offsets[cut[c]], na = atoms_of(c);
+        if (na) {
+            // (one hipMemcpy2DAsync of three rows for x, y, z a fixed distance apart runs at the link's rate by itself -
+            // tools/microbench_copy2d.hip - but is a kernel: behind the occlusion kernels it waits for CUs, and the call
+            // took 6.5 instead of 5.1 ms)
+            RS_HIP(ctx, hipMemcpyAsync(bx[k]->p, x + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
+            RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
+        }
+        return RSASA_OK;
+    }
+
+    // everything else of sub-batch c: radii (or their codes), ids (or their folds), rebased offsets
+    int upload(size_t c, hipStream_t st)
+    {
+        const int k = (int)(c % kSlots);
+        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
+        so[k].resize(s1 - s0 + 1);
+        for (size_t i = s0; i <= s1; i++) so[k][i - s0] = structure_offsets[i] - (uint32_t)a0;
+        if (na) {
+            if (!use_codes[c]) RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
+            if (!fold_ids && id && !drop_ids[c]) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
+        }
+        if (piped) {
+            // the sub-batch's pinned block (the workers have filled in ids and radius codes): table and offsets, one copy
+            char *blk = ctx->h_pack + pack[c].base;
+            if (use_codes[c]) std::memcpy(blk, ctx->radius_codec.table, kTableWords * 4);
+            if (want_res) {
+                const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
+                uint32_t *ro = reinterpret_cast<uint32_t *>(blk + pack[c].o_res);
+                for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
+            }
+            RS_HIP(ctx, hipMemcpyAsync(ctx->in_pack[k].p, blk, drop_ids[c] ? pack[c].o_id : pack[c].bytes, hipMemcpyHostToDevice, st));
+        } else if (want_res) {
+            const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
+            uint32_t *ro = ctx->slot[k].h_res;
+            for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
+            RS_HIP(ctx, hipMemcpyAsync(bo[k]->p, ro, (r1 - r0 + 1) * 4, hipMemcpyHostToDevice, st));
+        }
+        return RSASA_OK;
+    }
+
+    int drain(int k)  // output slot k's staged results to the caller's (pageable) arrays
+    {
+        if (!staged[k].active) return RSASA_OK;
+        RS_HIP(ctx, hipEventSynchronize(ctx->ev_d2h[k]));
+        const char *h = (const char *)ctx->h_out[k];
+        if (out_atom_sasa && !atoms_direct && staged[k].na)
+            std::memcpy(out_atom_sasa + staged[k].a0, h, staged[k].na * 4);
+        if (want_res && !res_direct && staged[k].nr)
+            std::memcpy(out_residue_sasa + staged[k].r0, h + stage_atoms, staged[k].nr * 4);
+        staged[k].active = false;
+        return RSASA_OK;
+    }
+
+    int copy_out(size_t c)  // sub-batch c's results (all its kernels have been waited for or ordered before)
+    {
+        hipStream_t dn = ctx->d2h_stream;
+        const int k = (int)(c % kSlots);
+        const size_t a0 = structure_offsets[cut[c]], na = atoms_of(c);
+        const size_t r0 = res_cut[c], nr = residues_of(c);
+        char *h = (char *)ctx->h_out[k];
+        if (out_atom_sasa && na)
+            RS_HIP(ctx, hipMemcpyAsync(atoms_direct ? (void *)(out_atom_sasa + a0) : (void *)h, oa[k]->p, na * 4,
+                                       hipMemcpyDeviceToHost, dn));
+        if (nr)
+            RS_HIP(ctx, hipMemcpyAsync(res_direct ? (void *)(out_residue_sasa + r0) : (void *)(h + stage_atoms),
+                                       orr[k]->p, nr * 4, hipMemcpyDeviceToHost, dn));
+        RS_HIP(ctx, hipEventRecord(ctx->ev_d2h[k], dn));
+        staged[k].active = stage_bytes != 0;
+        staged[k].a0 = a0; staged[k].na = na; staged[k].r0 = r0; staged[k].nr = nr;
+        return RSASA_OK;
+    }
+
+    // one sub-batch: upload, kernels, wait (rsasa_batch_wait re-runs with a larger cell array if needed), copy out
+    int run_one()
+    {
+        int rc;
+        hipStream_t st = ctx->stream;
+        unsigned long long order_job = 0;
+        if (host_check) {
+            IdOrder order;
+            ids_matter[0].store(0);
+            order.starts = structure_offsets;
+            order.n_starts = n_structures;
+            order.ids_matter = &ids_matter[0];
+            order_job = ctx->fold_pool->submit(id, nullptr, structure_offsets[n_structures], nullptr, nullptr, nullptr, order);
+            fold_drain.pool = ctx->fold_pool;
+            fold_drain.last = order_job;
+        }
+        if ((rc = upload_xyz(0, st))) return rc;
+        if (host_check) {
+            ctx->fold_pool->wait(order_job);
+            drop_ids[0] = !ids_matter[0].load();
+            if (drop_ids[0]) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+        }
+        if ((rc = upload(0, st))) return rc;
+        const size_t na = atoms_of(0), nr = residues_of(0);
+        if (na || nr) {
+            rsasa_device_batch_t bt{};
+            bt.x = dev_x[0];
+            bt.y = dev_y[0];
+            bt.z = dev_z[0];
+            bt.radius = (const float *)br[0]->p;
+            bt.id = id && !drop_ids[0] ? (const uint64_t *)bi[0]->p : nullptr;
+            bt.structure_offsets_host = so[0].data();
+            bt.n_structures = n_structures;
+            bt.n_atoms = na;
+            bt.residue_offsets = nr ? (const uint32_t *)bo[0]->p : nullptr;
+            bt.n_residues = nr;
+            bt.out_atom_sasa = (float *)oa[0]->p;
+            bt.out_residue_sasa = nr ? (float *)orr[0]->p : nullptr;
+            bt.out_neighbor_counts = nullptr;
+            // (ids that do not rise are not yet ids that matter: the device's own check - its hash tables for ids in no order -
+            // still runs on them; the host's pass only ever proves the droppable case)
+            if ((rc = batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr, false))) return rc;
+            if ((rc = rsasa_batch_wait(ctx))) return rc;
+        }
+        if ((rc = copy_out(0))) return rc;
+        if ((rc = drain(0))) return rc;
+        RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
+        return RSASA_OK;
+    }
+
+    // ---- several sub-batches ----
+    struct Attempt {  // what one pass over the sub-batches finds out
+        uint64_t need_cells = 0;
+        int err = RSASA_OK;
+        bool used[kSlots] = {};
+    };
+
+    void check(int k, Attempt &at)  // status of the sub-batch that used host slot k (its event has been waited for)
+    {
+        const BatchStatus stt = *ctx->slot[k].h_status;
+        if (stt.grid_too_large && !at.err)
+            at.err = fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "a structure's cell grid exceeds 2^31 cells (coordinates too sparse)");
+        if (stt.bad_input && !at.err)
+            at.err = fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius + max radius must be a positive finite number");
+        if (stt.overflow) at.need_cells = std::max<uint64_t>(at.need_cells, stt.total_cells);
+        else ctx->tuning.deferred_hint = stt.deferred;
+        if (!stt.overflow && ctx->slot[k].ids_check) {
+            ctx->ids_drop_hint = !stt.ids_needed;
+            ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
+            if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+        }
+    }
+
+    // all sub-batches' folds and radius codes, in order, while the uploads follow behind (the previous attempt's copies
+    // out of the pinned blocks have all been waited for)
+    void submit_coding_jobs()
+    {
+        if (!(fold_ids || code_radii)) return;
+        if (code_radii) ctx->radius_codec.reset();
+        for (size_t c = 0; c < n_sub; c++) {
+            const size_t a0 = structure_offsets[cut[c]], na = atoms_of(c);
+            char *blk = ctx->h_pack + pack[c].base;
+            IdOrder order;
+            ids_matter[c].store(0);
+            if (fold_ids && check_ids) {
+                order.starts = structure_offsets + cut[c];
+                order.n_starts = cut[c + 1] - cut[c];
+                order.first = (uint32_t)a0;
+                order.ids_matter = &ids_matter[c];
+            }
+            fold_job[c] = ctx->fold_pool->submit(fold_ids ? id + a0 : nullptr,
+                                                 fold_ids ? reinterpret_cast<uint32_t *>(blk + pack[c].o_id) : nullptr, na,
+                                                 radius + a0, code_radii ? reinterpret_cast<uint8_t *>(blk + pack[c].o_r8) : nullptr,
+                                                 code_radii ? &ctx->radius_codec : nullptr, order);
+        }
+        fold_drain.pool = ctx->fold_pool;
+        fold_drain.last = fold_job[n_sub - 1];
+    }
+
+    // sub-batch c: its uploads on the copy stream, its kernels behind them on one of the two launch streams, its results
+    // out behind those
+    int launch_sub_batch(size_t c, Attempt &at)
+    {
+        int rc;
+        hipStream_t cp = ctx->copy_stream, dn = ctx->d2h_stream;
+        const int k = (int)(c % kSlots);
+        if (at.used[k]) {
+            // slot k (host segments / status, input and output buffers) was sub-batch c - kSlots's
+            RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
+            check(k, at);
+            if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
+        }
+        tr.rec(k, 0, cp);
+        if ((rc = upload_xyz(c, cp))) return rc;
+        if (fold_ids || code_radii) ctx->fold_pool->wait(fold_job[c]);
+        use_codes[c] = code_radii && !ctx->radius_codec.failed.load();
+        drop_ids[c] = fold_ids && check_ids && !ids_matter[c].load();
+        if (drop_ids[c]) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
+        if (c == 0) tr.say("first sub-batch coded");
+        if ((rc = upload(c, cp))) return rc;
+        tr.rec(k, 1, cp);
+        RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
+        // consecutive sub-batches alternate between the context's two workspaces and launch streams: a
+        // sub-batch's grid build is then queued beside its predecessor's occlusion kernel and starts in its tail
+        // (enqueue_batch chains the occlusion kernels themselves)
+        const int w = (int)(c & 1);
+        hipStream_t st = w ? ctx->stream2 : ctx->stream;
+        RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
+        if (at.used[k]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k], 0));  // output slot k has left the device
+        const size_t s0 = cut[c], s1 = cut[c + 1], na = atoms_of(c), nr = residues_of(c);
+        Pending pd;
+        pd.batch.x = dev_x[k];
+        pd.batch.y = dev_y[k];
+        pd.batch.z = dev_z[k];
+        pd.batch.radius = (const float *)br[k]->p;
+        pd.batch.id = drop_ids[c] ? nullptr : fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
+        const char *dblk = (const char *)ctx->in_pack[k].p;
+        pd.id32 = fold_ids && !drop_ids[c] ? (const uint32_t *)(dblk + pack[c].o_id) : nullptr;
+        pd.ids_needed_known = fold_ids && check_ids && !drop_ids[c];
+        pd.batch.structure_offsets_host = so[k].data();
+        pd.batch.n_structures = s1 - s0;
+        pd.batch.n_atoms = na;
+        pd.batch.residue_offsets = nr ? (const uint32_t *)(dblk + pack[c].o_res) : nullptr;
+        pd.radius8 = use_codes[c] ? (const uint8_t *)(dblk + pack[c].o_r8) : nullptr;
+        pd.radius_table = use_codes[c] ? (const float *)dblk : nullptr;
+        pd.batch.n_residues = nr;
+        pd.batch.out_atom_sasa = (float *)oa[k]->p;
+        pd.batch.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
+        pd.batch.out_neighbor_counts = nullptr;
+        pd.probe = probe_radius;
+        pd.n_points = n_points;
+        pd.stream = st;
+        pd.ws = w;
+        tr.rec(k, 2, st);
+        if ((rc = enqueue_batch(ctx, pd, ctx->slot[k]))) return rc;
+        tr.rec(k, 3, st);
+        RS_HIP(ctx, hipEventRecord(ctx->ev_done[k], st));
+        RS_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_done[k], 0));
+        if ((rc = copy_out(c))) return rc;
+        at.used[k] = true;
+        if (H2HTrace::on()) tr.say(c + 1 == n_sub ? "last sub-batch enqueued" : "sub-batch enqueued");
+        return RSASA_OK;
+    }
+
+    // Several sub-batches on three streams: copy-in (sub-batch c + 1), compute (c), copy-out (c - 1).  kSlots
+    // sub-batches are in flight: the host queues the next one (upload, then kernels behind the upload's event) while
+    // earlier ones compute and never waits in between - the uploads, which are the longest leg (PCIe), follow each other
+    // without a gap.  A sub-batch's status block (host slot c % kSlots) is only read when its slot is needed again or at
+    // the end; if one of them reports that the cell array was too small, everything is drained, the array grows to the
+    // largest size reported and the call starts over (outputs are simply written again) - that happens on a context's
+    // first large call at most.
+    int run_piped()
+    {
+        int rc;
+        if (n_points == 0 || n_points > (1u << 24))
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "n_points must be in [1, 2^24]");
+        if (!(probe_radius >= 0.0f) || !std::isfinite(probe_radius))
+            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius must be finite and >= 0");
+        for (size_t sidx = 0; sidx < n_structures; sidx++)
+            if (structure_offsets[sidx] > structure_offsets[sidx + 1])
+                return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must be non-decreasing");
+        if (structure_offsets[0] != 0) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must span [0, n_atoms]");
+        hipStream_t cp = ctx->copy_stream;
+        if (!ctx->stream2) RS_HIP(ctx, new_stream(ctx, &ctx->stream2, 2));
+        for (int attempt = 0;; attempt++) {
+            Attempt at;
+            LinkHold turn;  // (released without an event on an error return)
+            submit_coding_jobs();
+            // (the coding jobs run while this call waits for its turn on the link)
+            RS_HIP(ctx, turn.take(ctx, cp));
+            tr.say("turn on the link taken");
+            for (size_t c = 0; c < n_sub; c++)
+                if ((rc = launch_sub_batch(c, at))) return rc;
+            turn.pass(cp);  // the next call's uploads follow this one's last
+            tr.say("turn passed on");
+            for (int k = 0; k < kSlots; k++) {
+                if (!at.used[k]) continue;
+                RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
+                check(k, at);
+                if ((rc = drain(k))) return rc;
+            }
+            RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
+            tr.say("all done");
+            tr.device_side(n_sub);
+            if (at.err) return at.err;
+            if (!at.need_cells) return RSASA_OK;
+            if (at.need_cells >= 0xFFFFFFF0ull || attempt >= 3)
+                return fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "batch needs more than 2^32 grid cells; split it");
+            ctx->cell_capacity = at.need_cells + at.need_cells / 8 + 1024;
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
 int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float *y,
                                const float *z, const float *radius, const uint64_t *id,
                                const uint32_t *structure_offsets, size_t n_structures,
@@ -332,35 +985,6 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
 
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     RS_DEVICE(ctx);
-    static const bool h2h_trace = tuning_env("RSASA_H2H_TRACE") != nullptr;  // host-side phases of a pipelined call, to stderr
-    const auto tr_t0 = std::chrono::steady_clock::now();
-    // (calls of several contexts on one clock; with the trace on, a reference event ties the device's clock to it)
-    static const auto epoch = std::chrono::steady_clock::now();
-    static hipEvent_t tr_ref = nullptr;
-    static double tr_ref_host_us = 0;
-    static std::mutex tr_mu;
-    if (h2h_trace) {
-        std::lock_guard<std::mutex> lkt(tr_mu);
-        if (!tr_ref && hipEventCreate(&tr_ref) == hipSuccess) {
-            (void)hipEventRecord(tr_ref, ctx->stream);
-            (void)hipEventSynchronize(tr_ref);
-            tr_ref_host_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - epoch).count();
-        }
-        for (auto &row : ctx->tr_ev)
-            for (hipEvent_t &e : row)
-                if (!e) (void)hipEventCreate(&e);
-    }
-    auto tr_rec = [&](int k, int i, hipStream_t s) {
-        if (h2h_trace && ctx->tr_ev[k][i]) (void)hipEventRecord(ctx->tr_ev[k][i], s);
-    };
-    auto tr = [&](const char *what) {
-        if (h2h_trace) {
-            const auto now = std::chrono::steady_clock::now();
-            std::fprintf(stderr, "h2h ctx %p at %9.1f us, %8.1f us into the call: %s\n", (void *)ctx,
-                         std::chrono::duration<double, std::micro>(now - epoch).count(),
-                         std::chrono::duration<double, std::micro>(now - tr_t0).count(), what);
-        }
-    };
     if (ctx->n_pending && (rc = wait_pending(ctx))) return rc;
     if (ctx->small_path) {
         SmallSource in;
@@ -370,489 +994,12 @@ int rsasa_calculate_sasa_batch(rsasa_context_t *ctx, const float *x, const float
                                   out_residue_sasa);
         if (rc != kNotSmall) return rc;
     }
-
     if ((rc = ensure_copy_streams(ctx))) return rc;
-    // Large batches are cut into sub-batches of whole structures (and whole residues) whose
-    // host-to-device copies run on a second stream into a second set of input buffers while the
-    // previous sub-batch computes: the PCIe transfer hides behind the kernels.
-    size_t kSubAtoms = 1500000;  // smallest sub-batch worth its own launch sequence
-    if (const char *v = tuning_env("RSASA_SUB_ATOMS")) kSubAtoms = (size_t)std::max(100000, std::atoi(v));
-    std::vector<size_t> cut{0};        // structure indices where sub-batches begin / end
-    if (N >= 2 * kSubAtoms && n_structures > 1) {
-        // (a worker of a stream of host batches: the NEXT call's uploads hide a call's fill and drain, so two sub-batches
-        // - one upload running beside one half's kernels - are enough, and every sub-batch fewer is a grid build fewer
-        // between the occlusion kernels: HostStream)
-        size_t max_sub = ctx->stream_sub_batches ? ctx->stream_sub_batches : 8;
-        if (const char *v = tuning_env("RSASA_SUB_BATCHES")) max_sub = (size_t)std::max(2, std::atoi(v));
-        const size_t n_sub = std::min<size_t>(max_sub, N / kSubAtoms);
-        // The link is the longest leg.  The first sub-batch's upload is not hidden behind anything, and nothing hides
-        // the last one's kernels: each gets half a share (RSASA_H2H_TAIL=0: only the first).
-        static const bool half_tail = !(tuning_env("RSASA_H2H_TAIL") && std::atoi(tuning_env("RSASA_H2H_TAIL")) == 0);
-        const size_t first = half_tail ? N / (2 * n_sub - 2) : N / (2 * n_sub - 1);
-        const size_t share = half_tail ? 2 * first : (N - first) / (n_sub - 1);
-        auto boundary = [&](size_t k) { return first + (k - 1) * share; };  // first atom of sub-batch k >= 1
-        size_t next = 1;
-        for (size_t sidx = 1; sidx < n_structures && next < n_sub; sidx++) {
-            const size_t a0 = structure_offsets[sidx];
-            if (a0 < boundary(next)) continue;
-            if (want_res && !std::binary_search(residue_offsets, residue_offsets + n_residues + 1, (uint32_t)a0))
-                continue;  // a residue spans this structure boundary: cut later
-            cut.push_back(sidx);
-            while (next < n_sub && boundary(next) <= a0) next++;
-        }
-    }
-    cut.push_back(n_structures);
-    size_t max_atoms = 1, max_res = 1;
-    std::vector<size_t> res_cut(cut.size(), 0);
-    for (size_t c = 0; c + 1 < cut.size(); c++) {
-        max_atoms = std::max<size_t>(max_atoms, structure_offsets[cut[c + 1]] - structure_offsets[cut[c]]);
-        if (want_res) {
-            res_cut[c + 1] = c + 2 == cut.size()
-                                 ? n_residues
-                                 : (size_t)(std::lower_bound(residue_offsets, residue_offsets + n_residues + 1,
-                                                             structure_offsets[cut[c + 1]]) - residue_offsets);
-            max_res = std::max(max_res, res_cut[c + 1] - res_cut[c]);
-        }
-    }
-    const bool piped = cut.size() > 2;
-    const size_t n_sub = cut.size() - 1;
-    constexpr size_t kTableWords = 256;  // a sub-batch's offsets block on the device: radius table | residue offsets
-    constexpr int kSlots = rsasa_context::kSlots;
-    const int n_slots = piped ? (int)std::min<size_t>((size_t)kSlots, n_sub) : 1;
-    DeviceBuffer *bx[kSlots] = {&ctx->in_x}, *by[kSlots] = {&ctx->in_y}, *bz[kSlots] = {&ctx->in_z}, *br[kSlots] = {&ctx->in_r};
-    DeviceBuffer *bi[kSlots] = {&ctx->in_id}, *bo[kSlots] = {&ctx->in_res}, *oa[kSlots] = {&ctx->atom_sasa}, *orr[kSlots] = {&ctx->out_res};
-    for (int k = 1; k < kSlots; k++) {
-        rsasa_context::MoreSlot &m = ctx->more[k - 1];
-        bx[k] = &m.x; by[k] = &m.y; bz[k] = &m.z; br[k] = &m.r; bi[k] = &m.id; bo[k] = &m.res; oa[k] = &m.atom_sasa; orr[k] = &m.out_res;
-    }
-    const float *dev_x[kSlots] = {}, *dev_y[kSlots] = {}, *dev_z[kSlots] = {};
-    for (int k = 0; k < n_slots; k++) {
-        if ((rc = reserve(ctx, *bx[k], max_atoms * 4))) return rc;
-        if ((rc = reserve(ctx, *by[k], max_atoms * 4))) return rc;
-        if ((rc = reserve(ctx, *bz[k], max_atoms * 4))) return rc;
-        dev_x[k] = (const float *)bx[k]->p; dev_y[k] = (const float *)by[k]->p; dev_z[k] = (const float *)bz[k]->p;
-        if ((rc = reserve(ctx, *br[k], max_atoms * 4))) return rc;
-        if (id && !piped && (rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;  // (pipelined: below, unless the ids are folded)
-        if (want_res && !piped && (rc = reserve(ctx, *bo[k], (max_res + 1) * 4))) return rc;
-        if ((rc = reserve(ctx, *oa[k], max_atoms * 4))) return rc;
-        if (want_res && (rc = reserve(ctx, *orr[k], max_res * 4))) return rc;
-    }
-
-    // Ids on the pipelined path: the link is the longest leg, and the matrix-core kernel only looks at 32-bit folds
-    // of the ids.  With the caller's ids in pinned memory the host folds them (a few worker threads, one sub-batch
-    // ahead of the uploads) and 4 bytes per atom cross the link instead of 8; the general kernel reads the few full
-    // ids it needs (atoms whose folds collide) straight from the caller's array, mapped into the device's
-    // address space.  Pageable ids, or a sub-batch the per-atom kernels take: the 64-bit ids are uploaded.
-    const uint64_t *id_mapped = nullptr;
-    bool fold_ids = false;
-    if (piped && id && !tuning_env("RSASA_NO_ID_FOLD")) {
-        Lattice lat_probe;
-        void *dp = nullptr;
-        if (n_points >= 1 && n_points <= (1u << 24) && get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
-            hipHostGetDevicePointer(&dp, const_cast<uint64_t *>(id), 0) == hipSuccess && dp) {
-            fold_ids = true;
-            for (size_t c = 0; c + 1 < cut.size(); c++)
-                fold_ids &= occlusion_uses_mx(ctx->tuning, lat_probe,
-                                              (uint32_t)(structure_offsets[cut[c + 1]] - structure_offsets[cut[c]]));
-            id_mapped = (const uint64_t *)dp;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
-    // Radii on the pipelined path: one-byte codes into the table of the batch's distinct radii (RadiusCodec), coded by
-    // the same worker threads.
-    const bool code_radii = piped && !tuning_env("RSASA_NO_RADIUS_CODES");
-    // the sub-batches' pinned blocks: radius table | residue offsets | folded ids | radius codes, 16-byte aligned parts
-    struct Pack { size_t base = 0, o_res = 0, o_id = 0, o_r8 = 0, bytes = 0; };
-    std::vector<Pack> pack(cut.size());
-    if (piped) {
-        auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
-        size_t total = 0, largest = 0;
-        for (size_t c = 0; c + 1 < cut.size(); c++) {
-            const size_t na = structure_offsets[cut[c + 1]] - structure_offsets[cut[c]];
-            const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
-            Pack &pk = pack[c];
-            pk.base = total;
-            pk.o_res = kTableWords * 4;
-            // (the folded ids last: a sub-batch whose ids turn out not to matter is uploaded without them)
-            pk.o_r8 = pk.o_res + up16(want_res ? (nr + 1) * 4 : 0);
-            pk.o_id = pk.o_r8 + up16(code_radii ? na : 0);
-            pk.bytes = pk.o_id + up16(fold_ids ? na * 4 : 0);
-            total += pk.bytes;
-            largest = std::max(largest, pk.bytes);
-        }
-        for (int k = 0; k < n_slots; k++)
-            if ((rc = reserve(ctx, ctx->in_pack[k], largest))) return rc;
-        if (total > ctx->h_pack_cap) {
-            if (ctx->h_pack) {
-                RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-                RS_HIP(ctx, hipHostFree(ctx->h_pack));
-                ctx->h_pack = nullptr;
-                ctx->h_pack_cap = 0;
-            }
-            const size_t cap = total + total / 4;
-            RS_HIP(ctx, hipHostMalloc((void **)&ctx->h_pack, cap, hipHostMallocDefault));
-            ctx->h_pack_cap = cap;
-        }
-    }
-    // Ids that are all different within their structure change nothing (BatchView::ids_check).  The pipelined path's
-    // coding workers look while they fold; one large sub-batch is checked by the same workers while its coordinates
-    // cross the link (then its 8 bytes of id per atom stay on the host); anything smaller is checked on the device.
-    const bool check_ids = id && !tuning_env("RSASA_NO_ID_CHECK");
-    bool host_check = false;
-    if (!piped && check_ids && cut.size() == 2 && structure_offsets[n_structures] >= 262144u && n_points >= 1 && n_points <= (1u << 24)) {
-        Lattice lat_probe;
-        host_check = get_lattice(ctx, n_points, &lat_probe) == RSASA_OK &&
-                     occlusion_uses_mx(ctx->tuning, lat_probe, structure_offsets[n_structures]);
-    }
-    if ((fold_ids || code_radii || host_check) && !ctx->fold_pool) {
-        unsigned nt = std::thread::hardware_concurrency() / 4;
-        if (const char *v = tuning_env("RSASA_FOLD_THREADS")) nt = (unsigned)std::atoi(v);
-        // ONE pool per device for all its contexts: two contexts with a stream of host batches between them (or
-        // process_files' pair) would otherwise run two pools of sixteen threads against each other - under a CPU quota
-        // (the measurement boxes: 16 CPUs) both are throttled, a sub-batch's coding takes 8 ms instead of 1 and its upload
-        // waits for it.  Jobs are worked off in the order they were submitted, whoever submitted them.
-        static std::mutex pools_mu;
-        static FoldPool *pools[64] = {};
-        {
-            std::lock_guard<std::mutex> lkp(pools_mu);
-            const int d = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
-            if (!pools[d]) pools[d] = new (std::nothrow) FoldPool(std::min(16u, std::max(2u, nt)), ctx->node);  // (lives as long as the process)
-            ctx->fold_pool = pools[d];
-        }
-        if (!ctx->fold_pool) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "fold pool");
-    }
-    std::vector<unsigned long long> fold_job(cut.size(), 0);
-    // (no fold job may outlive this call: the workers read the caller's id array)
-    struct FoldDrain {
-        FoldPool *pool = nullptr;
-        unsigned long long last = 0;
-        ~FoldDrain() { if (pool) pool->wait(last); }
-    } fold_drain;
-
-    // Results leave on their own stream while the next sub-batch computes.  A destination in
-    // pinned (page-locked) host memory takes the copy directly; a pageable one gets it through
-    // pinned staging, moved to its place by this thread once the copy has landed.
-    auto is_pinned = [](const void *p) {
-        hipPointerAttribute_t at{};
-        if (!p || hipPointerGetAttributes(&at, p) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        return at.type == hipMemoryTypeHost;
-    };
-    const bool atoms_direct = !out_atom_sasa || is_pinned(out_atom_sasa);
-    const bool res_direct = !want_res || is_pinned(out_residue_sasa);
-    const size_t stage_atoms = (out_atom_sasa && !atoms_direct) ? max_atoms * 4 : 0;
-    const size_t stage_bytes = stage_atoms + ((want_res && !res_direct) ? max_res * 4 : 0);
-    for (int k = 0; k < n_slots && stage_bytes; k++) {
-        if (stage_bytes <= ctx->h_out_cap[k]) continue;
-        if (ctx->h_out[k]) {
-            RS_HIP(ctx, hipStreamSynchronize(ctx->d2h_stream));
-            RS_HIP(ctx, hipHostFree(ctx->h_out[k]));
-            ctx->h_out[k] = nullptr;
-            ctx->h_out_cap[k] = 0;
-        }
-        RS_HIP(ctx, hipHostMalloc(&ctx->h_out[k], stage_bytes + stage_bytes / 4, hipHostMallocDefault));
-        ctx->h_out_cap[k] = stage_bytes + stage_bytes / 4;
-    }
-
-    // host copies of the rebased offsets stay alive until their sub-batch has been waited for
-    std::vector<uint32_t> so[kSlots];
-    for (int k = 0; k < n_slots && want_res && !piped; k++) {
-        rsasa_context::HostSlot &hs = ctx->slot[k];
-        if (max_res + 1 <= hs.h_res_cap) continue;
-        if (hs.h_res) {
-            RS_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-            RS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            RS_HIP(ctx, hipHostFree(hs.h_res));
-            hs.h_res = nullptr;
-            hs.h_res_cap = 0;
-        }
-        const size_t cap = max_res + 1 + max_res / 4;
-        RS_HIP(ctx, hipHostMalloc((void **)&hs.h_res, cap * sizeof(uint32_t), hipHostMallocDefault));
-        hs.h_res_cap = cap;
-    }
-    for (int k = 0; k < n_slots && piped && id && !fold_ids; k++)
-        if ((rc = reserve(ctx, *bi[k], max_atoms * 8))) return rc;
-    tr("setup done");
-    std::vector<char> use_codes(cut.size(), 0);  // sub-batch c's radii travel as codes (decided once its coding job is done)
-    // sub-batch c's ids stay on the host: those of each of its structures increase strictly, so they are all different and
-    // change nothing (IdOrder; found by the workers that fold them)
-    std::vector<char> drop_ids(cut.size(), 0);
-    std::unique_ptr<std::atomic<int>[]> ids_matter(new (std::nothrow) std::atomic<int>[cut.size()]);
-    if (!ids_matter) return fail(ctx, RSASA_ERR_OUT_OF_MEMORY, "id flags");
-    // the coordinates of a sub-batch do not wait for its coding job (ids, radius codes): they are queued first, and the
-    // first sub-batch's start crossing the link while its block is still being written
-    auto upload_xyz = [&](size_t c, hipStream_t st) -> int {
-        const int k = (int)(c % kSlots);
-        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
-        if (na) {
-            // (one hipMemcpy2DAsync of three rows for x, y, z a fixed distance apart runs at the link's rate by itself -
-            // tools/microbench_copy2d.hip - but is a kernel: behind the occlusion kernels it waits for CUs, and the call
-            // took 6.5 instead of 5.1 ms)
-            RS_HIP(ctx, hipMemcpyAsync(bx[k]->p, x + a0, na * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(by[k]->p, y + a0, na * 4, hipMemcpyHostToDevice, st));
-            RS_HIP(ctx, hipMemcpyAsync(bz[k]->p, z + a0, na * 4, hipMemcpyHostToDevice, st));
-        }
-        return RSASA_OK;
-    };
-    auto upload = [&](size_t c, hipStream_t st) -> int {
-        const int k = (int)(c % kSlots);
-        const size_t s0 = cut[c], s1 = cut[c + 1], a0 = structure_offsets[s0], na = structure_offsets[s1] - a0;
-        so[k].resize(s1 - s0 + 1);
-        for (size_t i = s0; i <= s1; i++) so[k][i - s0] = structure_offsets[i] - (uint32_t)a0;
-        if (na) {
-            if (!use_codes[c]) RS_HIP(ctx, hipMemcpyAsync(br[k]->p, radius + a0, na * 4, hipMemcpyHostToDevice, st));
-            if (!fold_ids && id && !drop_ids[c]) RS_HIP(ctx, hipMemcpyAsync(bi[k]->p, id + a0, na * 8, hipMemcpyHostToDevice, st));
-        }
-        if (piped) {
-            // the sub-batch's pinned block (the workers have filled in ids and radius codes): table and offsets, one copy
-            char *blk = ctx->h_pack + pack[c].base;
-            if (use_codes[c]) std::memcpy(blk, ctx->radius_codec.table, kTableWords * 4);
-            if (want_res) {
-                const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
-                uint32_t *ro = reinterpret_cast<uint32_t *>(blk + pack[c].o_res);
-                for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
-            }
-            RS_HIP(ctx, hipMemcpyAsync(ctx->in_pack[k].p, blk, drop_ids[c] ? pack[c].o_id : pack[c].bytes, hipMemcpyHostToDevice, st));
-        } else if (want_res) {
-            const size_t r0 = res_cut[c], r1 = res_cut[c + 1];
-            uint32_t *ro = ctx->slot[k].h_res;
-            for (size_t i = r0; i <= r1; i++) ro[i - r0] = residue_offsets[i] - (uint32_t)a0;
-            RS_HIP(ctx, hipMemcpyAsync(bo[k]->p, ro, (r1 - r0 + 1) * 4, hipMemcpyHostToDevice, st));
-        }
-        return RSASA_OK;
-    };
-    auto enqueue = [&](size_t c) -> int {
-        const int k = (int)(c % kSlots);
-        const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
-        const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
-        rsasa_device_batch_t bt{};
-        bt.x = dev_x[k];
-        bt.y = dev_y[k];
-        bt.z = dev_z[k];
-        bt.radius = (const float *)br[k]->p;
-        bt.id = id && !drop_ids[c] ? (const uint64_t *)bi[k]->p : nullptr;
-        bt.structure_offsets_host = so[k].data();
-        bt.n_structures = s1 - s0;
-        bt.n_atoms = na;
-        bt.residue_offsets = nr ? (const uint32_t *)bo[k]->p : nullptr;
-        bt.n_residues = nr;
-        bt.out_atom_sasa = (float *)oa[k]->p;
-        bt.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
-        bt.out_neighbor_counts = nullptr;
-        if (!(na || nr)) return RSASA_OK;
-        // (a verdict of the host's own check goes along: the device does not look at the ids again)
-        return batch_enqueue(ctx, &bt, probe_radius, n_points, nullptr, host_check && id && !drop_ids[c]);
-    };
-    // staged results of output slot k that still have to be moved to the caller's arrays
-    struct Staged { bool active = false; size_t a0 = 0, na = 0, r0 = 0, nr = 0; } staged[kSlots];
-    auto drain = [&](int k) -> int {
-        if (!staged[k].active) return RSASA_OK;
-        RS_HIP(ctx, hipEventSynchronize(ctx->ev_d2h[k]));
-        const char *h = (const char *)ctx->h_out[k];
-        if (out_atom_sasa && !atoms_direct && staged[k].na)
-            std::memcpy(out_atom_sasa + staged[k].a0, h, staged[k].na * 4);
-        if (want_res && !res_direct && staged[k].nr)
-            std::memcpy(out_residue_sasa + staged[k].r0, h + stage_atoms, staged[k].nr * 4);
-        staged[k].active = false;
-        return RSASA_OK;
-    };
-
-    hipStream_t st = ctx->stream, dn = ctx->d2h_stream;
-    auto copy_out = [&](size_t c) -> int {  // sub-batch c's results (all its kernels have been waited for or ordered before)
-        const int k = (int)(c % kSlots);
-        const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
-        const size_t r0 = res_cut[c], nr = want_res ? res_cut[c + 1] - r0 : 0;
-        char *h = (char *)ctx->h_out[k];
-        if (out_atom_sasa && na)
-            RS_HIP(ctx, hipMemcpyAsync(atoms_direct ? (void *)(out_atom_sasa + a0) : (void *)h, oa[k]->p, na * 4,
-                                       hipMemcpyDeviceToHost, dn));
-        if (nr)
-            RS_HIP(ctx, hipMemcpyAsync(res_direct ? (void *)(out_residue_sasa + r0) : (void *)(h + stage_atoms),
-                                       orr[k]->p, nr * 4, hipMemcpyDeviceToHost, dn));
-        RS_HIP(ctx, hipEventRecord(ctx->ev_d2h[k], dn));
-        staged[k].active = stage_bytes != 0;
-        staged[k].a0 = a0; staged[k].na = na; staged[k].r0 = r0; staged[k].nr = nr;
-        return RSASA_OK;
-    };
-    if (!piped) {
-        // one sub-batch: upload, kernels, wait (re-runs with a larger cell array if needed), copy out
-        unsigned long long order_job = 0;
-        if (host_check) {
-            IdOrder order;
-            ids_matter[0].store(0);
-            order.starts = structure_offsets;
-            order.n_starts = n_structures;
-            order.ids_matter = &ids_matter[0];
-            order_job = ctx->fold_pool->submit(id, nullptr, structure_offsets[n_structures], nullptr, nullptr, nullptr, order);
-            fold_drain.pool = ctx->fold_pool;
-            fold_drain.last = order_job;
-        }
-        if ((rc = upload_xyz(0, st))) return rc;
-        if (host_check) {
-            ctx->fold_pool->wait(order_job);
-            drop_ids[0] = !ids_matter[0].load();
-            if (drop_ids[0]) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
-        }
-        if ((rc = upload(0, st))) return rc;
-        if ((rc = enqueue(0))) return rc;
-        const size_t na = structure_offsets[cut[1]], nr = want_res ? res_cut[1] : 0;
-        if ((na || nr) && (rc = rsasa_batch_wait(ctx))) return rc;
-        if ((rc = copy_out(0))) return rc;
-        if ((rc = drain(0))) return rc;
-        RS_HIP(ctx, hipStreamSynchronize(dn));
-        return RSASA_OK;
-    }
-
-    // Several sub-batches on three streams: copy-in (sub-batch c + 1), compute (c), copy-out (c - 1).
-    // kSlots sub-batches are in flight: the host queues the next one (upload, then kernels behind the
-    // upload's event) while earlier ones compute and never waits in between - the uploads, which are the
-    // longest leg (PCIe), follow each other without a gap.  A
-    // sub-batch's status block (host slot c % kSlots) is only read when its slot is needed again or at
-    // the end; if one of them reports that the cell array was too small, everything is drained, the
-    // array grows to the largest size reported and the call starts over (outputs are simply
-    // written again) - that happens on a context's first large call at most.
-    if (n_points == 0 || n_points > (1u << 24))
-        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "n_points must be in [1, 2^24]");
-    if (!(probe_radius >= 0.0f) || !std::isfinite(probe_radius))
-        return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius must be finite and >= 0");
-    for (size_t sidx = 0; sidx < n_structures; sidx++)
-        if (structure_offsets[sidx] > structure_offsets[sidx + 1])
-            return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must be non-decreasing");
-    if (structure_offsets[0] != 0) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "structure_offsets must span [0, n_atoms]");
-    hipStream_t cp = ctx->copy_stream;
-    if (!ctx->stream2) RS_HIP(ctx, new_stream(ctx, &ctx->stream2, 2));
-    for (int attempt = 0;; attempt++) {
-        uint64_t need_cells = 0;
-        int err = RSASA_OK;
-        LinkHold turn;  // (released without an event on an error return)
-        auto check = [&](int k) {  // status of the sub-batch that used host slot k (its event has been waited for)
-            const BatchStatus stt = *ctx->slot[k].h_status;
-            if (stt.grid_too_large && !err)
-                err = fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "a structure's cell grid exceeds 2^31 cells (coordinates too sparse)");
-            if (stt.bad_input && !err)
-                err = fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "probe_radius + max radius must be a positive finite number");
-            if (stt.overflow) need_cells = std::max<uint64_t>(need_cells, stt.total_cells);
-            else ctx->tuning.deferred_hint = stt.deferred;
-            if (!stt.overflow && ctx->slot[k].ids_check) {
-                ctx->ids_drop_hint = !stt.ids_needed;
-                ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
-                if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
-            }
-        };
-        bool used[kSlots] = {};
-        if (fold_ids || code_radii) {
-            // all sub-batches' folds and radius codes, in order, while the uploads follow behind (the previous
-            // attempt's copies out of the pinned blocks have all been waited for)
-            if (code_radii) ctx->radius_codec.reset();
-            for (size_t c = 0; c < n_sub; c++) {
-                const size_t a0 = structure_offsets[cut[c]], na = structure_offsets[cut[c + 1]] - a0;
-                char *blk = ctx->h_pack + pack[c].base;
-                IdOrder order;
-                ids_matter[c].store(0);
-                if (fold_ids && check_ids) {
-                    order.starts = structure_offsets + cut[c];
-                    order.n_starts = cut[c + 1] - cut[c];
-                    order.first = (uint32_t)a0;
-                    order.ids_matter = &ids_matter[c];
-                }
-                fold_job[c] = ctx->fold_pool->submit(fold_ids ? id + a0 : nullptr,
-                                                     fold_ids ? reinterpret_cast<uint32_t *>(blk + pack[c].o_id) : nullptr, na,
-                                                     radius + a0, code_radii ? reinterpret_cast<uint8_t *>(blk + pack[c].o_r8) : nullptr,
-                                                     code_radii ? &ctx->radius_codec : nullptr, order);
-            }
-            fold_drain.pool = ctx->fold_pool;
-            fold_drain.last = fold_job[n_sub - 1];
-        }
-        // (the coding jobs above run while this call waits for its turn on the link)
-        RS_HIP(ctx, turn.take(ctx, cp));
-        tr("turn on the link taken");
-        for (size_t c = 0; c < n_sub; c++) {
-            const int k = (int)(c % kSlots);
-            if (used[k]) {
-                // slot k (host segments / status, input and output buffers) was sub-batch c - kSlots's
-                RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
-                check(k);
-                if ((rc = drain(k))) return rc;  // its staged results, if the destination is pageable
-            }
-            tr_rec(k, 0, cp);
-            if ((rc = upload_xyz(c, cp))) return rc;
-            if (fold_ids || code_radii) ctx->fold_pool->wait(fold_job[c]);
-            use_codes[c] = code_radii && !ctx->radius_codec.failed.load();
-            drop_ids[c] = fold_ids && check_ids && !ids_matter[c].load();
-            if (drop_ids[c]) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
-            if (c == 0) tr("first sub-batch coded");
-            if ((rc = upload(c, cp))) return rc;
-            tr_rec(k, 1, cp);
-            RS_HIP(ctx, hipEventRecord(ctx->ev_copy[k], cp));
-            // consecutive sub-batches alternate between the context's two workspaces and launch streams: a
-            // sub-batch's grid build is then queued beside its predecessor's occlusion kernel and starts in its tail
-            // (enqueue_batch chains the occlusion kernels themselves)
-            const int w = (int)(c & 1);
-            hipStream_t st = w ? ctx->stream2 : ctx->stream;
-            RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_copy[k], 0));
-            if (used[k]) RS_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_d2h[k], 0));  // output slot k has left the device
-            const size_t s0 = cut[c], s1 = cut[c + 1], na = structure_offsets[s1] - structure_offsets[s0];
-            const size_t nr = want_res ? res_cut[c + 1] - res_cut[c] : 0;
-            Pending pd;
-            pd.batch.x = dev_x[k];
-            pd.batch.y = dev_y[k];
-            pd.batch.z = dev_z[k];
-            pd.batch.radius = (const float *)br[k]->p;
-            pd.batch.id = drop_ids[c] ? nullptr : fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
-            const char *dblk = (const char *)ctx->in_pack[k].p;
-            pd.id32 = fold_ids && !drop_ids[c] ? (const uint32_t *)(dblk + pack[c].o_id) : nullptr;
-            pd.ids_needed_known = fold_ids && check_ids && !drop_ids[c];
-            pd.batch.structure_offsets_host = so[k].data();
-            pd.batch.n_structures = s1 - s0;
-            pd.batch.n_atoms = na;
-            pd.batch.residue_offsets = nr ? (const uint32_t *)(dblk + pack[c].o_res) : nullptr;
-            pd.radius8 = use_codes[c] ? (const uint8_t *)(dblk + pack[c].o_r8) : nullptr;
-            pd.radius_table = use_codes[c] ? (const float *)dblk : nullptr;
-            pd.batch.n_residues = nr;
-            pd.batch.out_atom_sasa = (float *)oa[k]->p;
-            pd.batch.out_residue_sasa = nr ? (float *)orr[k]->p : nullptr;
-            pd.batch.out_neighbor_counts = nullptr;
-            pd.probe = probe_radius;
-            pd.n_points = n_points;
-            pd.stream = st;
-            pd.ws = w;
-            tr_rec(k, 2, st);
-            if ((rc = enqueue_batch(ctx, pd, ctx->slot[k]))) return rc;
-            tr_rec(k, 3, st);
-            RS_HIP(ctx, hipEventRecord(ctx->ev_done[k], st));
-            RS_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_done[k], 0));
-            if ((rc = copy_out(c))) return rc;
-            used[k] = true;
-            if (h2h_trace) tr(c + 1 == n_sub ? "last sub-batch enqueued" : "sub-batch enqueued");
-        }
-        turn.pass(cp);  // the next call's uploads follow this one's last
-        tr("turn passed on");
-        for (int k = 0; k < kSlots; k++) {
-            if (!used[k]) continue;
-            RS_HIP(ctx, hipEventSynchronize(ctx->ev_done[k]));
-            check(k);
-            if ((rc = drain(k))) return rc;
-        }
-        RS_HIP(ctx, hipStreamSynchronize(dn));
-        tr("all done");
-        if (h2h_trace && tr_ref && n_sub <= (size_t)kSlots) {
-            // the device's side of the same call: each sub-batch's uploads and kernels on the host trace's clock
-            for (size_t c = 0; c < n_sub; c++) {
-                float t[4] = {};
-                for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&t[i], tr_ref, ctx->tr_ev[c][i]);
-                std::fprintf(stderr, "h2h ctx %p device: sub-batch %zu uploads %9.1f .. %9.1f us, kernels %9.1f .. %9.1f us\n", (void *)ctx, c,
-                             tr_ref_host_us + t[0] * 1e3, tr_ref_host_us + t[1] * 1e3, tr_ref_host_us + t[2] * 1e3, tr_ref_host_us + t[3] * 1e3);
-            }
-        }
-        if (err) return err;
-        if (!need_cells) return RSASA_OK;
-        if (need_cells >= 0xFFFFFFF0ull || attempt >= 3)
-            return fail(ctx, RSASA_ERR_GRID_TOO_LARGE, "batch needs more than 2^32 grid cells; split it");
-        ctx->cell_capacity = need_cells + need_cells / 8 + 1024;
-    }
+    HostBatch call(ctx, x, y, z, radius, id, structure_offsets, n_structures, probe_radius, n_points, out_atom_sasa, residue_offsets,
+                   n_residues, out_residue_sasa);
+    call.plan();
+    if ((rc = call.stage())) return rc;
+    return call.piped ? call.run_piped() : call.run_one();
 }
 
 // ---- a stream of host batches (ABI 3) ----
