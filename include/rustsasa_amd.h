@@ -32,7 +32,7 @@ extern "C" {
  * "the" batch); rsasa_batch_wait_all, rsasa_context_get_simd_width, rsasa_context_bind_thread added.
  * 3: rsasa_host_batch_enqueue / _wait / _wait_all (a stream of host batches), rsasa_context_clone_settings,
  *    rsasa_context_ids_dropped added;
- * 4: rsasa_context_set_call_combining, rsasa_call_combining_stats added; rsasa_host_batch_enqueue with eight batches
+ * 4: rsasa_context_set_call_combining, rsasa_call_combining_stats, rsasa_context_ids_kept added; rsasa_host_batch_enqueue with eight batches
  *    queued returns RSASA_ERR_QUEUE_FULL at once (it used to wait for the oldest batch and then fail);
  * nothing else changed, nothing removed. */
 #define RSASA_ABI_VERSION 4
@@ -297,10 +297,18 @@ int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out);
  * increase strictly within every structure (atom serials, indices) are found
  * by one comparison per atom, on the device or by the host's coding threads;
  * 64-bit ids in no order (hashes) that are on the device go through a hash
- * table per structure (up to 27 648 atoms per structure).  This statistic
- * counts the (sub-)batches of the context, its stream of host batches
- * included, that ran so. */
+ * table per structure (up to 27 648 atoms per structure); ids the host has
+ * folded to 32 bits (a pipelined host call's pinned ids) through the same
+ * tables on their folds.  The verdict is each STRUCTURE's: one with two equal
+ * ids (a file whose serial numbers repeat), or one nobody could check, keeps
+ * its ids and runs in the kernels' instantiation with ids, the others of the
+ * same batch without (ABI 4; a single such structure used to put the whole
+ * batch on the slower path).  rsasa_context_ids_dropped counts the
+ * (sub-)batches of the context, its stream of host batches included, in which
+ * NO structure kept its ids; rsasa_context_ids_kept gives the number of
+ * structures that kept theirs in the context's last checked (sub-)batch. */
 int rsasa_context_ids_dropped(rsasa_context_t *ctx, uint64_t *out_batches);
+int rsasa_context_ids_kept(rsasa_context_t *ctx, uint64_t *out_structures);
 
 /* ---- utilities --------------------------------------------------------- */
 

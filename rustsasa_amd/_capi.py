@@ -91,6 +91,7 @@ SYMBOLS = {
     "rsasa_context_enable_timing": (C.c_int, [_vp, C.c_int]),
     "rsasa_context_get_timings": (C.c_int, [_vp, C.POINTER(Timings)]),
     "rsasa_context_ids_dropped": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "rsasa_context_ids_kept": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "rsasa_context_set_call_combining": (C.c_int, [_vp, C.c_int]),
     "rsasa_call_combining_stats": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rsasa_sphere_points": (C.c_int, [C.c_size_t, _vp, _vp, _vp]),

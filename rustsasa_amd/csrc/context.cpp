@@ -388,6 +388,8 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     if ((rc = reserve(ctx, W.sid_sorted, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, W.deferred_list, std::max<size_t>(N, 1) * 4))) return rc;
     if ((rc = reserve(ctx, W.claim, kClaimBytes))) return rc;
+    const size_t ids_seg_words = (N + 2047) / 2048;  // (BatchView::ids_seg: a bit per 64 atoms, two bitmaps)
+    if (has_id && (rc = reserve(ctx, W.ids_seg, 2 * ids_seg_words * 4 + 16))) return rc;
     if (has_tail && (rc = reserve(ctx, W.cell_of, std::max<size_t>(N, 1) * 4))) return rc;  // (batch-wide binning only)
     if ((rc = reserve(ctx, W.rank_of, std::max<size_t>(N, 1) * 4))) return rc;
     // + 1 end marker, + 3: k_zero_cells / k_scan_* access whole 16-byte vectors up to the end marker
@@ -416,7 +418,9 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.id32 = pd.id32;
     // ids that are all different within their structure change nothing: checked on the device (BatchView::ids_check)
     // unless the host has looked already (pd.ids_needed_known: the host paths check before they upload)
-    v.ids_check = (has_id && !pd.id32 && !pd.ids_needed_known && !keep_ids && !tuning_env("RSASA_NO_ID_CHECK")) ? 1u : 0u;
+    // (host-folded ids are checked as well: folds that differ are ids that differ, and a structure with two equal folds
+    // simply keeps its ids)
+    v.ids_check = (has_id && !pd.ids_needed_known && !keep_ids && !tuning_env("RSASA_NO_ID_CHECK")) ? 1u : 0u;
     hs.ids_check = v.ids_check != 0u;
     v.large_sids = reinterpret_cast<const uint32_t *>((const Segment *)W.segments.p + n_seg);
     v.n_large = (uint32_t)n_large;
@@ -435,6 +439,8 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     v.sid_sorted = (uint32_t *)W.sid_sorted.p;
     v.deferred_list = (uint32_t *)W.deferred_list.p;
     v.claim = (uint32_t *)W.claim.p;
+    v.ids_seg = has_id ? (uint32_t *)W.ids_seg.p : nullptr;
+    v.ids_seg_words = (uint32_t)ids_seg_words;
     v.cell_of = (uint32_t *)W.cell_of.p;
     v.rank_of = (uint32_t *)W.rank_of.p;
     v.cells = (uint32_t *)W.cells.p;
@@ -541,7 +547,7 @@ int wait_one(rsasa_context *ctx, Pending &pd)
             // nothing was computed - the batch runs again, with its ids and without the check
             ctx->ids_drop_hint = false;
             ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
-            pd.ids_needed_known = true;
+            pd.solo_ok = false;  // (as a pair this time: every structure in the instantiation that is its own)
             pd.attempts++;
             int rc = enqueue_batch(ctx, pd, ctx->slot[pd.ws]);
             if (rc) {
@@ -555,6 +561,7 @@ int wait_one(rsasa_context *ctx, Pending &pd)
             if (ctx->slot[pd.ws].ids_check) {
                 ctx->ids_drop_hint = !stt.ids_needed;
                 ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
+                ctx->ids_kept_structures.store(stt.ids_needed, std::memory_order_relaxed);
                 if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
             }
             if (ctx->timing) {
@@ -772,7 +779,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
     if (ctx->d2h_stream) (void)hipStreamSynchronize(ctx->d2h_stream);
     for (DeviceBuffer *b : {&ctx->segments, &ctx->acc, &ctx->grids, &ctx->grid_sums, &ctx->sid_sorted, &ctx->deferred_list, &ctx->cell_of,
                             &ctx->rank_of, &ctx->cells, &ctx->windows, &ctx->scan_sums, &ctx->sorted_xyzr,
-                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa, &ctx->claim,
+                            &ctx->sorted_orig, &ctx->sorted_id, &ctx->sorted_id32, &ctx->status, &ctx->atom_sasa, &ctx->claim, &ctx->ws[0].ids_seg,
                             &ctx->in_x, &ctx->in_y, &ctx->in_z, &ctx->in_r, &ctx->in_id,
                             &ctx->in_res, &ctx->out_res, &ctx->out_k, &ctx->small_in, &ctx->small_out, &ctx->tr_xyz, &ctx->tr_r,
                             &ctx->tr_id, &ctx->tr_res})
@@ -799,7 +806,7 @@ int rsasa_context_destroy(rsasa_context_t *ctx)
         rsasa_context::Workspace &w1 = ctx->ws[1];
         for (DeviceBuffer *b : {&w1.segments, &w1.acc, &w1.grids, &w1.grid_sums, &w1.sid_sorted, &w1.deferred_list, &w1.cell_of, &w1.rank_of,
                                 &w1.cells, &w1.windows, &w1.scan_sums, &w1.sorted_xyzr, &w1.sorted_orig, &w1.sorted_id, &w1.sorted_id32,
-                                &w1.status, &w1.atom_sasa, &w1.claim})
+                                &w1.status, &w1.atom_sasa, &w1.claim, &w1.ids_seg})
             release(*b);
     }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -906,6 +913,15 @@ int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out)
     if (!ctx->timings_valid)
         return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "no timed batch has completed");
     *out = ctx->timings;
+    return RSASA_OK;
+}
+
+int rsasa_context_ids_kept(rsasa_context_t *ctx, uint64_t *out_structures)
+{
+    int rc = resolve_ctx(ctx);
+    if (rc) return rc;
+    if (!out_structures) return fail(ctx, RSASA_ERR_INVALID_ARGUMENT, "out_structures is NULL");
+    *out_structures = ctx->ids_kept_structures.load(std::memory_order_relaxed);
     return RSASA_OK;
 }
 

@@ -24,6 +24,8 @@ struct StructGrid {
     uint32_t odd_radii;            // bit 0: some radius of the structure lies outside [0, 64] or is NaN, or some coordinate is
                                    // NaN, infinite or beyond 1e8 (the matrix-core occlusion kernel leaves such structures
                                    // to the general kernel: its padding records must be finite vectors);
+                                   // bit 1 (BatchView::ids_check): the structure keeps its ids - two of them are equal, or nobody
+                                   // could check (k_bounds, k_ids_distinct); bit 2: its ids are in no order (k_bounds);
                                    // bits 8..9: log2 of the x-cell block its atom groups share (grid_group_shift)
 };
 static_assert(sizeof(StructGrid) == 64, "StructGrid layout");
@@ -36,7 +38,8 @@ struct StructAcc {
     int max_r;
     uint32_t n_atoms;      // atoms of the structure (sum over its bounds workgroups)
     uint32_t first_atom;   // smallest atom index of the structure
-    int odd_radii;         // nonzero: a radius outside [0, 64] or NaN, a coordinate non-finite or beyond 1e8 (see StructGrid::odd_radii)
+    int odd_radii;         // bit 0: a radius outside [0, 64] or NaN, a coordinate non-finite or beyond 1e8; bits 1, 2: the ids' verdict
+                           // (see StructGrid::odd_radii)
 };
 
 // A contiguous slice of one structure handled by one bounds workgroup.
@@ -65,8 +68,9 @@ struct BatchStatus {
     uint32_t tail_atom_base;  // their first position in the cell-sorted arrays (= atoms of the LDS-binned structures)
     uint32_t n_windows;       // entries of BatchView::windows (work list of k_sort_window)
     uint64_t grid_cells;      // cells of all grids (statistic)
-    uint32_t ids_needed;      // BatchView::ids_check: 0 = the ids of every structure are all different, so "another atom
-                              // with my id" never happens - the batch runs as one without ids
+    uint32_t ids_needed;      // BatchView::ids_check: the structures that keep their ids (StructGrid::odd_radii bit 1).  0 = the ids of
+                              // every structure are all different, so "another atom with my id" never happens - the batch
+                              // runs as one without ids; otherwise each structure runs in the instantiation that is its own
     uint32_t ids_unordered;   // bit 0, the same: some id does not rise above its predecessor's (k_bounds); k_ids_distinct then looks
                               // for equal ids structure by structure.  Bit 1: the one occlusion launch of the batch was the id-less
                               // instantiation and the ids turned out to matter (OcclusionChain::solo): nothing was computed
@@ -133,6 +137,9 @@ struct BatchView {
                                   // k_sort_window: rank_of = sorted position of the atoms a workgroup's registers do not hold
     uint32_t *deferred_list;      // atoms k_occlusion_fast left to the general kernel (BatchStatus::deferred entries)
     uint32_t *claim;              // k_occlusion_mx: block counters of its persistent waves, kClaimBytes (launch_occlusion zeroes them)
+    uint32_t *ids_seg;            // BatchView::ids_check: two bitmaps of ids_seg_words words, a bit per 64 cell-sorted atoms - "an atom of a
+    uint32_t ids_seg_words;       // structure that keeps its ids is among them" and "... of one that does not" (k_ids_segments): a workgroup of
+                                  // k_occlusion_mx whose atoms hold nothing of its instantiation's returns before it has fetched anything else
     uint32_t *cells;              // cell starts (cell_capacity + 1 entries of 32 bits; see StructGrid::cell_base)
     uint64_t cell_capacity;
     uint4 *windows;               // (structure, window, first atom, atoms) of every k_sort_window workgroup

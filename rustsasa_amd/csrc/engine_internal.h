@@ -313,7 +313,7 @@ struct rsasa_context {
     // workspace 0.
     struct Workspace {
         DeviceBuffer segments, acc, grids, grid_sums, sid_sorted, deferred_list, cell_of, rank_of, cells, windows, scan_sums,
-            sorted_xyzr, sorted_orig, sorted_id, sorted_id32, status, atom_sasa, claim;
+            sorted_xyzr, sorted_orig, sorted_id, sorted_id32, status, atom_sasa, claim, ids_seg;
         hipEvent_t ev[5] = {};  // timing (rsasa_context_enable_timing): start, grid built, occlusion starts / has run, sums done
         hipEvent_t ev_occ = nullptr;  // the batch's occlusion kernels have run (the other workspace's batch starts its own
         bool occ_recorded = false;    // behind it: two occlusion kernels sharing the CUs only slow each other down)
@@ -373,6 +373,7 @@ struct rsasa_context {
         bool ids_check = false;         // the batch that last used the slot ran with BatchView::ids_check
     } slot[kSlots];
     std::atomic<uint64_t> ids_dropped{0};         // batches / sub-batches that ran without their ids (rsasa_context_ids_dropped)
+    std::atomic<uint64_t> ids_kept_structures{0}; // structures of the last checked (sub-)batch that kept their ids (rsasa_context_ids_kept)
     bool ids_drop_hint = true;                    // what the last checked batch did (OcclusionChain::expect_ids_dropped)
     bool ids_unordered_hint = false;              // its ids were in no order: the next batch brings the id tables (BatchView::ids_tables)
     hipEvent_t ev_done[kSlots] = {};              // all work of the sub-batch in slot k has been executed

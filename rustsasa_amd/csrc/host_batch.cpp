@@ -807,6 +807,7 @@ struct HostBatch {
         if (!stt.overflow && ctx->slot[k].ids_check) {
             ctx->ids_drop_hint = !stt.ids_needed;
             ctx->ids_unordered_hint = (stt.ids_unordered & 1u) != 0u;
+            ctx->ids_kept_structures.store(stt.ids_needed, std::memory_order_relaxed);
             if (!stt.ids_needed) ctx->ids_dropped.fetch_add(1, std::memory_order_relaxed);
         }
     }
@@ -876,7 +877,9 @@ struct HostBatch {
         pd.batch.id = drop_ids[c] ? nullptr : fold_ids ? id_mapped + structure_offsets[s0] : id ? (const uint64_t *)bi[k]->p : nullptr;
         const char *dblk = (const char *)ctx->in_pack[k].p;
         pd.id32 = fold_ids && !drop_ids[c] ? (const uint32_t *)(dblk + pack[c].o_id) : nullptr;
-        pd.ids_needed_known = fold_ids && check_ids && !drop_ids[c];
+        // (ids that do not rise are not yet ids that matter: the device looks at the folds - a hash table per structure once
+        // the context has seen ids in no order - and every structure whose folds all differ runs without its ids)
+        pd.ids_needed_known = false;
         pd.batch.structure_offsets_host = so[k].data();
         pd.batch.n_structures = s1 - s0;
         pd.batch.n_atoms = na;

@@ -22,9 +22,10 @@ namespace {
 
 // ------------------------------------------------------ per-structure grid --
 
-__global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *status, uint32_t ids_needed)
+__global__ void k_init_acc(StructAcc *acc, uint32_t n_structures, BatchStatus *status, uint32_t ids_needed, uint32_t *ids_seg, uint32_t ids_seg_words)
 {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = s; ids_seg && i < 2u * ids_seg_words; i += gridDim.x * blockDim.x) ids_seg[i] = 0u;  // (BatchView::ids_seg)
     if (s == 0) {
         status->overflow = 0;
         status->grid_too_large = 0;
@@ -61,13 +62,17 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     float mr = 0.0f;
     bool odd_r = false;  // a radius outside [0, 64] (or NaN), a coordinate beyond 1e8 (or NaN / infinite): see StructGrid::odd_radii
     if (b.ids_check) {
-        // BatchView::ids_check: an id that is not larger than its predecessor's in the same structure
+        // BatchView::ids_check: an id that is not larger than its predecessor's in the same structure (host-folded ids
+        // stand for themselves: folds that rise are ids that differ).  The verdict is the STRUCTURE's (StructAcc::odd_radii
+        // bit 2: its ids are in no order; bit 1: it keeps its ids), the batch's flags only say "some structure".
         bool falls = false;
         for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x)
-            if (i > seg.begin || seg.continues) falls |= b.id[i] <= b.id[i - 1u];
+            if (i > seg.begin || seg.continues) falls |= load_id(b.id, b.id32, i) <= load_id(b.id, b.id32, i - 1u);
         if (falls) {
             b.status->ids_unordered = 1u;
-            if (!b.ids_tables) b.status->ids_needed = 1u;  // (nobody will look closer this time)
+            // (no tables in this batch: nobody will look closer this time - the structure keeps its ids; ids_needed counts them)
+            const int before = atomicOr(&b.acc[seg.sid].odd_radii, b.ids_tables ? 4 : 6);
+            if (!b.ids_tables && (before & 2) == 0) atomicAdd(&b.status->ids_needed, 1u);
         }
     }
     for (uint32_t i = seg.begin + threadIdx.x; i < seg.end; i += blockDim.x) {
@@ -109,50 +114,65 @@ __global__ __launch_bounds__(256) void k_bounds(BatchView b)
     if (ballot64(odd_r) != 0ull && lane_id() == 0) atomicOr(&b.acc[seg.sid].odd_radii, 1);
 }
 
-// BatchView::ids_check, second step - only when k_bounds found ids that do not rise (hashes: what SASAOptions::process
-// passes, options.rs:183): are the ids of every structure all different?  One workgroup per structure puts its ids into
-// an open-addressing table in LDS (the entry is the atom's number; an occupied slot is decided on the full 64-bit ids, so
-// the answer is exact whatever the hash does); the first equal pair raises BatchStatus::ids_needed.  Two launches share
-// the structures by size (device_types.h kIdSlotsSmall / kIdSlotsLarge): one workgroup per structure with the small
-// table - larger structures are not its business -, and one per entry of the host's list of larger structures with the
-// large one (a workgroup that only finds out that it has nothing to do would still wait for 144 KB of LDS).
+// BatchView::ids_check, second step - for the structures whose ids k_bounds found in no order (hashes: what
+// SASAOptions::process passes, options.rs:183): are the ids of the structure all different?  One workgroup per structure
+// puts its ids into an open-addressing table in LDS (the entry is the atom's number; an occupied slot is decided on the
+// ids themselves - the full 64-bit ids, so the answer is exact whatever the hash does; or the host's 32-bit folds, where
+// equal folds count as "maybe equal ids": such a structure keeps its ids, which is always correct).  The first equal pair
+// marks THE STRUCTURE as one that keeps its ids (StructGrid::odd_radii bit 1) and raises BatchStatus::ids_needed ("some
+// structure does").  Two launches share the structures by size (device_types.h kIdSlotsSmall / kIdSlotsLarge): one
+// workgroup per structure with the small table - larger structures are not its business, except that it marks the ones
+// too large for either table -, and one per entry of the host's list of larger structures with the large one (a
+// workgroup that only finds out that it has nothing to do would still wait for 144 KB of LDS).
 template <uint32_t SLOTS, uint32_t THREADS, bool LARGE>
 __global__ __launch_bounds__(THREADS) void k_ids_distinct(BatchView b)
 {
-    // The way out is taken by the WHOLE workgroup or by none of it: other workgroups of this launch raise ids_needed while
-    // this one runs, so waves that read the flags for themselves could part ways - some gone without having zeroed their
-    // share of the table, the others past the barrier with those slots holding whatever the LDS held (and then following
-    // a garbage entry far outside the id column).  One thread reads the flags, everybody reads its verdict.
-    __shared__ uint32_t s_go;
-    if (threadIdx.x == 0u) s_go = (b.status->ids_unordered != 0u && b.status->ids_needed == 0u) ? 1u : 0u;
-    __syncthreads();
-    if (s_go == 0u) return;
-    if (b.ids_too_big) {
-        if (blockIdx.x == 0u && threadIdx.x == 0u) b.status->ids_needed = 1u;
+    const uint32_t s = LARGE ? b.large_sids[blockIdx.x] : blockIdx.x;
+    // (the structure's own flags, final since k_bounds / k_grid_params: every thread reads the same words - no workgroup
+    // of this launch changes another structure's)
+    if ((b.grids[s].odd_radii & 6u) != 4u) return;  // ids that rise, or a structure that keeps its ids already
+    const uint32_t n = b.acc[s].n_atoms, a0 = b.acc[s].first_atom;
+    if (n < 2u) return;
+    if (n > (LARGE ? kIdAtomsLarge : kIdAtomsSmall)) {
+        if (!LARGE && n > kIdAtomsLarge && threadIdx.x == 0u) {  // too large for either table: its ids stay in play
+            atomicOr(&b.grids[s].odd_radii, 2u);
+            atomicAdd(&b.status->ids_needed, 1u);
+        }
         return;
     }
-    const uint32_t s = LARGE ? b.large_sids[blockIdx.x] : blockIdx.x;
-    const uint32_t n = b.acc[s].n_atoms, a0 = b.acc[s].first_atom;
-    if (n < 2u || (!LARGE && n > kIdAtomsSmall)) return;
     __shared__ uint32_t s_tab[SLOTS];
     for (uint32_t k = threadIdx.x; k < SLOTS; k += THREADS) s_tab[k] = 0u;
     __syncthreads();
-    const uint64_t *__restrict__ id = b.id + a0;
     bool equal = false;
     for (uint32_t i = threadIdx.x; i < n && !equal; i += THREADS) {
-        const uint64_t mine = id[i];
+        const uint64_t mine = load_id(b.id, b.id32, a0 + i);
         uint32_t h = (uint32_t)(((uint64_t)(fold_id(mine) * 0x9E3779B1u) * SLOTS) >> 32);
         for (;;) {
             const uint32_t there = atomicCAS(&s_tab[h], 0u, i + 1u);
             if (there == 0u) break;
-            // (second guard: an entry is the number of one of this structure's atoms, or the slot counts as the batch's
-            // "ids stay in play" - never an address)
-            if (there > n) { equal = true; break; }
-            if (id[there - 1u] == mine) { equal = true; break; }
+            // (an entry is the number of one of this structure's atoms - anything else would count as an equal pair,
+            // never as an address)
+            if (there > n || load_id(b.id, b.id32, a0 + there - 1u) == mine) { equal = true; break; }
             h = h + 1u == SLOTS ? 0u : h + 1u;
         }
     }
-    if (equal) b.status->ids_needed = 1u;
+    if (equal && (atomicOr(&b.grids[s].odd_radii, 2u) & 2u) == 0u) atomicAdd(&b.status->ids_needed, 1u);  // (once per structure)
+}
+
+// BatchView::ids_seg: which runs of 64 cell-sorted atoms hold atoms of structures that keep their ids, and which hold
+// atoms of structures that do not (one thread per structure; the verdicts are final, the structures placed).
+__global__ __launch_bounds__(256) void k_ids_segments(BatchView b)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= b.n_structures) return;
+    const StructGrid g = b.grids[s];
+    if (!g.n_atoms) return;
+    uint32_t *bits = b.ids_seg + ((g.odd_radii & 2u) ? 0u : b.ids_seg_words);
+    const uint32_t s0 = g.sorted_base >> 6, s1 = (g.sorted_base + g.n_atoms - 1u) >> 6;
+    for (uint32_t w = s0 >> 5; w <= (s1 >> 5) && w < b.ids_seg_words; w++) {
+        const uint32_t lo = max(s0, w << 5) & 31u, hi = min(s1, (w << 5) + 31u) & 31u;
+        atomicOr(&bits[w], (0xFFFFFFFFu >> (31u - hi)) & (0xFFFFFFFFu << lo));
+    }
 }
 
 // SpatialGrid::new parameters (spatial_grid.rs:35-44 with cell_size from lib.rs:76).
@@ -193,7 +213,7 @@ __device__ __forceinline__ StructGrid make_grid(const StructAcc &a, float probe,
     // 16-bit LDS counters and positions: structures with fewer than 65536 atoms are binned in LDS,
     // one k_sort_window workgroup per window of kWindowCells cells; the others by the batch-wide kernels
     g.in_lds = a.n_atoms < kLdsMaxAtoms ? 1u : 0u;
-    g.odd_radii = (a.odd_radii != 0 ? 1u : 0u) | (grid_group_shift(a.n_atoms, (uint32_t)nc) << 8);
+    g.odd_radii = ((uint32_t)a.odd_radii & 7u) | (grid_group_shift(a.n_atoms, (uint32_t)nc) << 8);  // (bits 1, 2: the ids' verdict, k_bounds)
     return g;
 }
 
@@ -391,7 +411,6 @@ __global__ __launch_bounds__(sort_window_threads(SINGLE), SINGLE ? 4 : (RSASA_SO
     auto pr = [&](uint32_t i) { return load_radius(b.radius, b.radius8, b.radius_table, i); };
     const uint32_t *__restrict__ pid32 = b.id32;
     const uint64_t *__restrict__ pid = pid32 ? reinterpret_cast<const uint64_t *>(pid32) : b.id;  // (non-null: the batch has ids)
-    if (!SINGLE && b.ids_check && b.status->ids_needed == 0u) pid = nullptr;  // (all different: as good as none)
     uint32_t *__restrict__ rank_of = b.rank_of;  // sorted position of the atoms without a slot
     uint4 *stage = reinterpret_cast<uint4 *>(s_cnt);
     // ---- the structure's first kSlots * 1024 atoms (slot k of a thread: atom a0 + tid + 1024 k) ----
@@ -414,6 +433,7 @@ __global__ __launch_bounds__(sort_window_threads(SINGLE), SINGLE ? 4 : (RSASA_SO
         }
     }
     if (!SINGLE) g = b.grids[s];
+    if (!SINGLE && b.ids_check && (g.odd_radii & 2u) == 0u) pid = nullptr;  // (this structure's ids are all different: as good as none)
     const uint32_t dim_xy = g.dim_x * g.dim_y;
     const uint32_t n_cells = min(kWindowCells, g.n_cells - c0), n_words = (n_cells + 1u) >> 1;
     const bool last_window = c0 + n_cells == g.n_cells;
@@ -769,7 +789,7 @@ __global__ __launch_bounds__(256) void k_scatter(BatchView b)
         b.sorted_xyzr[pos] = make_float4(b.x[i], b.y[i], b.z[i], load_radius(b.radius, b.radius8, b.radius_table, i));
         b.sorted_orig[pos] = i;
         b.sid_sorted[pos] = s;
-        if (b.sorted_id32 && !(b.ids_check && b.status->ids_needed == 0u)) { const uint64_t v = load_id(b.id, b.id32, i); if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
+        if (b.sorted_id32 && !(b.ids_check && (b.grids[s].odd_radii & 2u) == 0u)) { const uint64_t v = load_id(b.id, b.id32, i); if (b.sorted_id) b.sorted_id[pos] = v; b.sorted_id32[pos] = fold_id(v); }
     }
 }
 
@@ -792,7 +812,7 @@ __global__ __launch_bounds__(256) void k_residue_sums(BatchView b)
 void launch_grid_prepare(const BatchView &b, hipStream_t stream)
 {
     hipLaunchKernelGGL(k_init_acc, dim3(cdiv(b.n_structures > 0 ? b.n_structures : 1, 256)), dim3(256), 0, stream,
-                       b.acc, b.n_structures, b.status, b.ids_check ? 0u : 1u);
+                       b.acc, b.n_structures, b.status, b.ids_check ? 0u : 1u, b.ids_check ? b.ids_seg : nullptr, b.ids_seg_words);
     if (b.n_segments)
         hipLaunchKernelGGL(k_bounds, dim3(b.n_segments), dim3(256), 0, stream, b);
     const uint32_t n_parts = cdiv(b.n_structures > 0 ? b.n_structures : 1, 256);
@@ -806,9 +826,10 @@ void launch_grid_prepare(const BatchView &b, hipStream_t stream)
         // launched when the context's last batch had such ids (BatchView::ids_tables), and last of the small kernels, where
         // the binning that follows waits for LDS anyway (in front of the grid kernels they held those up as well).
         hipLaunchKernelGGL((k_ids_distinct<kIdSlotsSmall, 256u, false>), dim3(b.n_structures), dim3(256), 0, stream, b);
-        if (b.n_large && !b.ids_too_big)
+        if (b.n_large)
             hipLaunchKernelGGL((k_ids_distinct<kIdSlotsLarge, 1024u, true>), dim3(b.n_large), dim3(1024), 0, stream, b);
     }
+    if (b.ids_check && b.ids_seg && b.n_structures) hipLaunchKernelGGL(k_ids_segments, dim3(n_parts), dim3(256), 0, stream, b);
 }
 
 // Binning of the structures with fewer than 65536 atoms: one workgroup per window of cells.  The

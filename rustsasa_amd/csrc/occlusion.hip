@@ -126,9 +126,9 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
     const uint32_t n_blocks = mx_persistent(MULTI) ? min(cdiv(n_atoms, NW * a3.atoms_per_wave), resident) : cdiv(n_atoms, NW * a3.atoms_per_wave);
     if (mx_persistent(MULTI)) (void)hipMemsetAsync(a3.claim, 0, 8u * kClaimStride * 4u, stream);  // (a failure shows as the launch's)
     if (has_id && a3.ids_check) {
-        // BatchView::ids_check: whether the ids matter is known on the device only - both instantiations are launched, the
-        // one that BatchStatus::ids_needed does not ask for returns at once (its workgroups touch nothing, the claim
-        // counters included).  The one the host expects to return goes first, in front of the chain's wait.
+        // BatchView::ids_check: which structures keep their ids is known on the device only - both instantiations are launched,
+        // each works on the structures that are its own (StructGrid::odd_radii bit 1), and the one with ids returns at once
+        // when there is none (its workgroups touch nothing, the claim counters included).
         const bool dropped = !chain || chain->expect_ids_dropped;
         if (chain && chain->solo && dropped) {
             // (the caller runs the batch again if the guess was wrong: OcclusionChain::solo)
@@ -136,12 +136,20 @@ void launch_mx(bool has_id, bool rem, uint32_t n_atoms, uint32_t lds_bytes, hipS
             only.ids_check = 2u;
             chain_begin(chain, stream);
             launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, only);
-        } else {
-            if (dropped) launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
-            else launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        } else if (dropped) {
+            // (the instantiation with ids is expected to return at once - no structure kept its ids last time -: in front of
+            // the chain's wait, where it runs beside the neighbour's kernel for nothing)
+            launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
             chain_begin(chain, stream);
-            if (dropped) launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
-            else launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+            // (persistent waves claim their blocks from counters: either launch of the pair may have worked through them)
+            if (mx_persistent(MULTI)) (void)hipMemsetAsync(a3.claim, 0, 8u * kClaimStride * 4u, stream);
+            launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+        } else {
+            // some structures keep their ids, the others do not: both launches work, each on the structures that are its own
+            chain_begin(chain, stream);
+            launch_mx1<NT, false, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
+            if (mx_persistent(MULTI)) (void)hipMemsetAsync(a3.claim, 0, 8u * kClaimStride * 4u, stream);
+            launch_mx1<NT, true, MULTI, NW>(rem, n_blocks, lds_bytes, stream, a3);
         }
     } else {
         chain_begin(chain, stream);

@@ -284,6 +284,12 @@ class Context:
         self._check(self._lib.rsasa_context_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timings._fields_}
 
+    def ids_kept(self) -> int:
+        """Structures of the context's last checked (sub-)batch that kept their ids (rsasa_context_ids_kept)."""
+        n = C.c_uint64(0)
+        self._check(self._lib.rsasa_context_ids_kept(self._h, C.byref(n)))
+        return int(n.value)
+
     def ids_dropped(self) -> int:
         """(Sub-)batches that ran without their ids because the ids of every structure increased strictly
         (rsasa_context_ids_dropped)."""

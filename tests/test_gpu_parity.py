@@ -1164,7 +1164,9 @@ def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch
                 if name in rises or (name in distinct and not pinned):
                     assert n_drop >= 2, (name, pinned, n_drop)      # every sub-batch
                 elif name in distinct:
-                    assert n_drop == 0, (name, pinned, n_drop)      # (pinned ids in no order travel as folds: nothing to prove them different with)
+                    # (pinned ids in no order travel as 32-bit folds: the device's tables prove the FOLDS of a structure
+                    # different - which proves the ids different - wherever no two folds collide)
+                    assert n_drop >= 1, (name, pinned, n_drop)
                 elif name.startswith("pair") or not pinned:
                     assert 1 <= n_drop, (name, pinned, n_drop)      # every sub-batch but the pair's
     # a structure too large for the hash table (more than 27 648 atoms) keeps ids in no order in play; rising ones still go
@@ -1332,3 +1334,80 @@ def test_rank_shard_of_the_eight_way_split(ctx):
     ctx.host_batch_wait_all()
     for a, rs in got:
         assert np.array_equal(a, want) and np.array_equal(rs, want_res)
+
+
+def test_the_verdict_on_ids_is_each_structures_own(monkeypatch):
+    """ABI 4: a structure whose ids repeat (a file whose serial numbers start over, an altloc pair hashed alike) keeps its
+    ids and runs in the kernels' instantiation with ids; the other structures of the same batch run without theirs -
+    a single such structure used to put the whole batch on the slower path (found on the reference's quality set, whose
+    real files hold repeated serials).  Rising ids and hashes, device-resident batches at 100 points and at 960 (the
+    persistent waves' block counters serve both launches of the pair), a host batch with pinned hashes cut into
+    sub-batches: every atom against the oracle, and the count of structures that kept their ids."""
+    import rustsasa_amd
+    import torch
+    b = bw.synthetic_proteome(125, seed=31)
+    so = b.structure_offsets.astype(np.int64)
+    rising = b.ids.copy()
+    hashed = b.ids * np.uint64(0x9E3779B97F4A7C15)
+
+    shown = {}
+
+    def pair_that_shows(s):
+        """(at, j): atom `at` of structure s takes the id of its near neighbour j, and a value of the structure changes"""
+        if s not in shown:
+            s0, s1 = int(so[s]), int(so[s + 1])
+            cols = (b.x[s0:s1], b.y[s0:s1], b.z[s0:s1], b.radius[s0:s1])
+            base = po.calculate_sasa_internal(*cols, None, PROBE, 100, 8)
+            for at in np.flatnonzero(base > 5.0)[10:40]:
+                d2 = (cols[0] - cols[0][at]) ** 2 + (cols[1] - cols[1][at]) ** 2 + (cols[2] - cols[2][at]) ** 2
+                d2[at] = np.inf
+                for j in np.argsort(d2)[:6]:
+                    ids = np.arange(1, s1 - s0 + 1, dtype=np.uint64)
+                    ids[at] = ids[j]
+                    if not np.array_equal(po.calculate_sasa_internal(*cols, ids, PROBE, 100, 8), base):
+                        shown[s] = (s0 + int(at), s0 + int(j))
+                        break
+                if s in shown:
+                    break
+            assert s in shown, s
+        return shown[s]
+
+    def with_pairs(ids, structures):
+        ids = ids.copy()
+        for s in structures:  # an atom takes a near neighbour's id, chosen so that a value changes: the test can tell
+            at, j = pair_that_shows(s)
+            ids[at] = ids[j]
+        return ids
+
+    cases = [("rising, pairs in 2 structures", with_pairs(rising, (7, 124)), 2), ("hashed, pair in the last structure", with_pairs(hashed, (124,)), 1),
+             ("hashed, none", hashed, 0), ("hashed, pairs in 3 structures", with_pairs(hashed, (0, 60, 124)), 3)]
+    wants = {}
+    for name, ids, _ in cases:
+        for n_points in (100, 960):
+            wants[(name, n_points)] = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, PROBE, n_points, 8, threads=0)
+    none = po.calculate_sasa_batch(b.x, b.y, b.z, b.radius, None, b.structure_offsets, PROBE, 100, 8, threads=0)
+    assert not np.array_equal(wants[(cases[0][0], 100)], none)  # (the pairs change values: the test can tell)
+    with rustsasa_amd.Context(0) as c:
+        for name, ids, kept in cases:
+            bb = bw.Batch(b.x, b.y, b.z, b.radius, ids, b.structure_offsets, b.residue_offsets)
+            for n_points in (100, 960):
+                for second in (False, True):  # (the hash tables join a batch once the context has seen ids in no order)
+                    n0 = c.ids_dropped()
+                    atom, _, _ = _device_run(c, bb, n_points=n_points, want_res=False)
+                    bad = np.flatnonzero(atom != wants[(name, n_points)])
+                    assert bad.size == 0, (name, n_points, second, bad.size, np.searchsorted(so, bad[:5], side="right") - 1)
+                assert c.ids_kept() == kept, (name, n_points, c.ids_kept())
+                assert c.ids_dropped() - n0 == (1 if kept == 0 else 0), (name, n_points)
+
+    def pin(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).pin_memory().numpy()
+
+    monkeypatch.setenv("RSASA_SUB_ATOMS", "60000")  # (read per call under RSASA_TUNING=1: several sub-batches of this batch)
+    with rustsasa_amd.Context(0) as c:
+        px, py, pz, pr = (pin(a) for a in (b.x, b.y, b.z, b.radius))
+        for name, ids, kept in cases[1:3]:
+            pid = pin(ids)
+            for second in (False, True):
+                atom, _ = c.calculate_sasa_batch(px, py, pz, pr, pid, b.structure_offsets, PROBE, 100)
+                assert np.array_equal(atom, wants[(name, 100)]), ("host, pipelined, pinned hashes", name, second)
+            assert c.ids_kept() == kept, (name, c.ids_kept())  # (of the last sub-batch, which holds the last structure)
