@@ -11,7 +11,8 @@
 #                              host batches against one call after the other
 #   pmc_uniform1m.txt          the same instruction-mix, matrix-pipe and GRBM_GUI_ACTIVE passes for the 1M-atom / 960-point dispatch
 #   bench_uniform1m.json, single_and_pcie.json, files_mode.json, files_mode_1500.json, files_mode_cif.json, bench_shard_of_8.json,
-#   two_in_flight.txt, bench_run2.json (a second default run at the end)
+#   two_in_flight.txt, bench_run2.json (a second default run at the end), per_call_combined.txt (the drop-in call alone and with call
+#   combining), files_end_to_end.json / _cif.json (4 363 files in -> 4 363 JSON files out)
 tag=${1:-round}
 out=gpurun_out/$tag
 mkdir -p $out
@@ -48,5 +49,8 @@ tools/microbench_clock > $out/microbench_clock.txt 2>&1
 H2H_REPS=5 python3 tools/bench_h2h_stream.py --api 12 2>/dev/null | tail -3 > $out/h2h_stream.txt
 H2H_SORTED=1 python3 tools/bench_h2h.py 8 2>/dev/null | tail -1 >> $out/h2h_stream.txt
 python3 tools/h2h_stream_trace.py 12 3 2> $out/h2h_trace.log > /dev/null; awk '/==== round 2/,0' $out/h2h_trace.log | grep "device:\|====" > $out/h2h_stream_trace.txt
+RSASA_TUNING=1 RSASA_COMBINE_TRACE=1 python3 tools/bench_per_call.py 1 1 16 c16 c64 s64 2>&1 | grep -v '^ *$' > $out/per_call_combined.txt
+python3 tools/bench_files.py --end-to-end --files 4363 --repeat 3 > $out/e2e.log 2>&1; tail -1 $out/e2e.log > $out/files_end_to_end.json
+python3 tools/bench_files.py --end-to-end --files 4363 --repeat 3 --format cif > $out/e2e_cif.log 2>&1; tail -1 $out/e2e_cif.log > $out/files_end_to_end_cif.json
 rm -rf $out/trace $out/pmc_a $out/pmc_b $out/pmc_c $out/pmc_d $out/pmc_e $out/pmc_g $out/pmc_fetch $out/pmc_write $out/pmc_tcc
 ls -la $out; cat $out/bench.json; cat $out/bench_under_rocprof.json; head -4 $out/kernel_stats.csv | cut -c1-160; cat $out/pmc.txt

@@ -10,13 +10,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-prefix = sys.argv[2] if len(sys.argv) > 2 else "round5_final"
+prefix = sys.argv[2] if len(sys.argv) > 2 else "round6_final"
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 names = {a: f"{prefix}_{a}" for a in ("bench.json", "bench_under_rocprof.json", "kernel_stats.csv", "pmc.txt",
                                         "bench_uniform1m.json", "single_and_pcie.json", "files_mode.json", "pmc_uniform1m.txt",
                                         "files_mode_1500.json", "files_mode_cif.json", "bench_shard_of_8.json", "two_in_flight.txt", "bench_run2.json",
-                                        "microbench_clock.txt", "h2h_stream.txt", "h2h_stream_trace.txt")}
+                                        "microbench_clock.txt", "h2h_stream.txt", "h2h_stream_trace.txt", "per_call_combined.txt", "files_end_to_end.json",
+                                        "files_end_to_end_cif.json")}
 for a, b in names.items():
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 10:
