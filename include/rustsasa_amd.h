@@ -297,7 +297,7 @@ int rsasa_context_get_timings(rsasa_context_t *ctx, rsasa_timings_t *out);
  * increase strictly within every structure (atom serials, indices) are found
  * by one comparison per atom, on the device or by the host's coding threads;
  * 64-bit ids in no order (hashes) that are on the device go through a hash
- * table per structure (up to 27 648 atoms per structure); ids the host has
+ * table per structure (up to 55 296 atoms per structure); ids the host has
  * folded to 32 bits (a pipelined host call's pinned ids) through the same
  * tables on their folds.  The verdict is each STRUCTURE's: one with two equal
  * ids (a file whose serial numbers repeat), or one nobody could check, keeps

@@ -238,7 +238,10 @@ constexpr uint32_t kScanBlocks = 1024;    // workgroups of the cell scan
 constexpr uint32_t kWindowCells = RSASA_WINDOW_CELLS;  // cells one k_sort_window workgroup bins (16-bit counters, 72 KiB: two per CU)
 // k_ids_distinct (BatchView::ids_check): a table of 8 192 slots in LDS for structures of up to 4 096 atoms (32 KB: several
 // workgroups per CU), one of 36 864 for up to 27 648 (144 KB, one workgroup per such structure)
-constexpr uint32_t kIdSlotsSmall = 8192, kIdAtomsSmall = 4096, kIdSlotsLarge = 36864, kIdAtomsLarge = 27648;
+// (the large table's entries are 16 bits wide - an atom's number within its structure, below 65 536 -: twice the slots in the
+// same 144 KB, which takes structures of up to 55 296 atoms; round 5's 32-bit entries stopped at 27 648, and the reference's own
+// quality set holds a complex of 32 500)
+constexpr uint32_t kIdSlotsSmall = 8192, kIdAtomsSmall = 4096, kIdSlotsLarge = 73728, kIdAtomsLarge = 55296;
 constexpr uint32_t kLdsMaxAtoms = 65536;  // structures with fewer atoms are binned in LDS (16-bit positions)
 
 // 16-bit entries a structure of n_cells cells takes in the cell array: its cells, the end marker,

@@ -140,15 +140,29 @@ __global__ __launch_bounds__(THREADS) void k_ids_distinct(BatchView b)
         }
         return;
     }
-    __shared__ uint32_t s_tab[SLOTS];
-    for (uint32_t k = threadIdx.x; k < SLOTS; k += THREADS) s_tab[k] = 0u;
+    // entries: the atom's number + 1 - 32 bits wide in the small table, 16 in the large one (two per word: a slot is taken
+    // by a compare-and-swap of the word that holds it)
+    constexpr uint32_t kWords = LARGE ? SLOTS / 2u : SLOTS;
+    __shared__ uint32_t s_tab[kWords];
+    for (uint32_t k = threadIdx.x; k < kWords; k += THREADS) s_tab[k] = 0u;
     __syncthreads();
+    auto take = [&](uint32_t slot, uint32_t value) -> uint32_t {  // 0: the slot was free and is `value`'s now; else who holds it
+        if (!LARGE) return atomicCAS(&s_tab[slot], 0u, value);
+        uint32_t *w = &s_tab[slot >> 1];
+        const uint32_t sh = (slot & 1u) * 16u;
+        for (;;) {
+            const uint32_t old = *(volatile uint32_t *)w;
+            const uint32_t there = (old >> sh) & 0xFFFFu;
+            if (there) return there;
+            if (atomicCAS(w, old, old | (value << sh)) == old) return 0u;
+        }
+    };
     bool equal = false;
     for (uint32_t i = threadIdx.x; i < n && !equal; i += THREADS) {
         const uint64_t mine = load_id(b.id, b.id32, a0 + i);
         uint32_t h = (uint32_t)(((uint64_t)(fold_id(mine) * 0x9E3779B1u) * SLOTS) >> 32);
         for (;;) {
-            const uint32_t there = atomicCAS(&s_tab[h], 0u, i + 1u);
+            const uint32_t there = take(h, i + 1u);
             if (there == 0u) break;
             // (an entry is the number of one of this structure's atoms - anything else would count as an equal pair,
             // never as an address)

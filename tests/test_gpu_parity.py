@@ -1169,8 +1169,9 @@ def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch
                     assert n_drop >= 1, (name, pinned, n_drop)
                 elif name.startswith("pair") or not pinned:
                     assert 1 <= n_drop, (name, pinned, n_drop)      # every sub-batch but the pair's
-    # a structure too large for the hash table (more than 27 648 atoms) keeps ids in no order in play; rising ones still go
-    big = bw.synthetic_uniform(40_000, seed=3)
+    # a structure too large for the hash table (more than 55 296 atoms: 16-bit entries, 144 KB) keeps ids in no order in play;
+    # rising ones still go
+    big = bw.synthetic_uniform(60_000, seed=3)
     with rustsasa_amd.Context(0) as c:
         for ids, dropped in ((big.ids * np.uint64(0x9E3779B97F4A7C15), 0), (big.ids * np.uint64(0x9E3779B97F4A7C15), 0), (big.ids, 1)):
             bb = bw.Batch(big.x, big.y, big.z, big.radius, ids, big.structure_offsets, big.residue_offsets)
@@ -1178,6 +1179,20 @@ def test_ids_that_cannot_matter_are_dropped_and_ones_that_do_are_not(monkeypatch
             assert np.array_equal(atom, po.calculate_sasa_batch(big.x, big.y, big.z, big.radius, ids, big.structure_offsets,
                                                                 PROBE, 100, 8, threads=0))
             assert c.ids_dropped() == dropped
+    # one that the large table takes since its entries are 16 bits wide (40 000 atoms; round 5's table stopped at 27 648): hashes
+    # are proven different once the tables are part of the batch, and a repeated id in it is found
+    mid = bw.synthetic_uniform(40_000, seed=4)
+    hashed = mid.ids * np.uint64(0x9E3779B97F4A7C15)
+    rep = hashed.copy()
+    rep[39_999] = rep[17]
+    with rustsasa_amd.Context(0) as c:
+        # (the first batch of a context: launched id-less alone, found to hold ids in no order, run again - by then WITH the tables)
+        for ids, kept in ((hashed, None), (hashed, 0), (rep, 1), (hashed, 0)):
+            bb = bw.Batch(mid.x, mid.y, mid.z, mid.radius, ids, mid.structure_offsets, mid.residue_offsets)
+            atom, _, _ = _device_run(c, bb, want_res=False)
+            assert np.array_equal(atom, po.calculate_sasa_batch(mid.x, mid.y, mid.z, mid.radius, ids, mid.structure_offsets,
+                                                                PROBE, 100, 8, threads=0))
+            assert kept is None or c.ids_kept() == kept, (kept, c.ids_kept())
     monkeypatch.setenv("RSASA_NO_ID_CHECK", "1")    # the switch that turns the check off: same values
     with rustsasa_amd.Context(0) as c:
         for name in ("rising", "pair_inside"):
