@@ -344,12 +344,10 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     size_t n_seg = 0;
     // (behind the segments, in the same upload: the structures whose ids k_ids_distinct's large table takes)
     size_t n_large = 0;
-    bool ids_too_big = false;
     for (size_t s = 0; s < S; s++) {
         const uint32_t b = bt.structure_offsets_host[s], e = bt.structure_offsets_host[s + 1];
         n_seg += (e - b + kSegmentAtoms - 1) / kSegmentAtoms;
         n_large += e - b > kIdAtomsSmall && e - b <= kIdAtomsLarge;
-        ids_too_big |= e - b > kIdAtomsLarge;
     }
     const size_t n_seg_all = n_seg + (n_large + 3) / 4;  // (four structure numbers per segment-sized entry)
     if (n_seg_all > hs.h_segments_cap) {
@@ -424,7 +422,6 @@ int enqueue_batch(rsasa_context *ctx, const Pending &pd, rsasa_context::HostSlot
     hs.ids_check = v.ids_check != 0u;
     v.large_sids = reinterpret_cast<const uint32_t *>((const Segment *)W.segments.p + n_seg);
     v.n_large = (uint32_t)n_large;
-    v.ids_too_big = ids_too_big ? 1u : 0u;
     v.ids_tables = ctx->ids_unordered_hint ? 1u : 0u;
     v.radius8 = pd.radius8;
     v.radius_table = pd.radius_table;

@@ -117,14 +117,14 @@ struct BatchView {
     float probe;
     // Ids only matter where two atoms of a structure share one (lib.rs:127: a neighbour with the atom's own id is
     // skipped).  1: k_bounds also checks that the ids of every structure increase strictly (what atom serials and indices
-    // do); if they do not (hashes), k_ids_distinct puts every structure's ids through a hash table in LDS; and while
-    // BatchStatus::ids_needed stays 0 every later kernel treats the batch as one WITHOUT ids - no id loads, no sorted
-    // copies, the occlusion kernel's id-less instantiation (4 % faster) - with identical results.  Set for batches with
-    // 64-bit device ids that the matrix-core kernel takes.
+    // do); where they do not (hashes), k_ids_distinct puts that structure's ids (or the host's 32-bit folds of them) through
+    // a hash table in LDS.  The verdict is each STRUCTURE's (StructGrid::odd_radii bit 1): one whose ids are all different
+    // is computed as one WITHOUT ids - no id loads, no sorted copies, the occlusion kernel's id-less instantiation (4 %
+    // faster) - with identical results; BatchStatus::ids_needed counts the others.  Set for batches with ids that the
+    // matrix-core kernel takes.
     uint32_t ids_check;
     const uint32_t *large_sids;    // k_ids_distinct: the structures of more than kIdAtomsSmall (and at most kIdAtomsLarge) atoms
     uint32_t n_large;
-    uint32_t ids_too_big;          // some structure has more than kIdAtomsLarge atoms: ids in no order stay in play
     uint32_t ids_tables;           // the k_ids_distinct launches are part of this batch (the context's last checked batch had
                                    // ids in no order); 0: they are not - their workgroups wait for LDS even to return -, and
                                    // ids that do not rise simply stay in play for this batch

@@ -505,3 +505,42 @@ def test_host_stream_under_stress():
     free1 = torch.cuda.mem_get_info()[0]
     assert abs(free1 - free0) < 96 * 2 ** 20, f"device memory {free0 >> 20} -> {free1 >> 20} MB"
     print(f"stress: {N_BATCHES} host batches from two threads in {time.time() - t0:.1f} s")
+
+
+def test_call_combining_opens_a_second_block_when_one_is_full():
+    """A combining block holds 196 608 atoms: fourteen threads that each bring a structure of 30 000 atoms (a call's
+    largest share is 32 768) cannot share one - the calls that do not fit open the next block, every block is led by the
+    call that opened it, and every value is the oracle's.  A call with more atoms than a share runs by itself."""
+    import rustsasa_amd
+    rng = np.random.default_rng(3)
+    structs = []
+    for k in range(3):
+        b = bw.synthetic_uniform(30_000 + 500 * k, seed=40 + k)
+        structs.append((b.x, b.y, b.z, b.radius, b.ids, po.calculate_sasa_internal(b.x, b.y, b.z, b.radius, b.ids, PROBE, 100, 8, threads=0)))
+    big = bw.synthetic_uniform(40_000, seed=50)
+    want_big = po.calculate_sasa_internal(big.x, big.y, big.z, big.radius, big.ids, PROBE, 100, 8, threads=0)
+    errors = []
+    b0, c0 = rustsasa_amd.Context.call_combining_stats(0)
+    with rustsasa_amd.Context(0) as c:
+        c.set_call_combining(50)
+
+        def work(tid):
+            try:
+                for it in range(6):
+                    x, y, z, r, ids, want = structs[(tid + it) % 3]
+                    if not np.array_equal(c.calculate_sasa_soa(x, y, z, r, ids, PROBE, 100), want):
+                        errors.append((tid, it))
+                if tid == 0 and not np.array_equal(c.calculate_sasa_soa(big.x, big.y, big.z, big.radius, big.ids, PROBE, 100), want_big):
+                    errors.append("the call that runs alone")
+            except Exception as e:  # noqa: BLE001
+                errors.append((tid, repr(e)))
+
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(14)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in threads)
+    b1, c1 = rustsasa_amd.Context.call_combining_stats(0)
+    assert errors == []
+    assert c1 - c0 == 14 * 6 and b1 - b0 >= (14 * 6 * 30_000) // 196_608  # (no block held more than it can)
