@@ -26,9 +26,9 @@ with rustsasa_amd.Context(0) as ctx:
     ctx.wait()
 v = k.cpu().numpy().astype(np.float64)
 q = np.percentile(v, [50, 90, 99, 100])
-print(%r, "mean %%.2f p50 %%d p90 %%d p99 %%d max %%d  frac==0 %%.3f  frac>16 %%.3f frac>32 %%.3f" %% (v.mean(), q[0], q[1], q[2], q[3], np.mean(v == 0), np.mean(v > 16), np.mean(v > 32)))
+print(%r, "mean %%.2f p50 %%d p90 %%d p99 %%d max %%d  frac==0 %%.3f  frac>16 %%.3f frac>32 %%.3f  1..4: %%s  5..8: %%.3f  9..16: %%.3f" %% (v.mean(), q[0], q[1], q[2], q[3], np.mean(v == 0), np.mean(v > 16), np.mean(v > 32), [round(float(np.mean(v == i)), 3) for i in (1, 2, 3, 4)], np.mean((v >= 5) & (v <= 8)), np.mean((v >= 9) & (v <= 16))))
 """
-names = {1: "S (survivors of phase A)", 2: "nA (near candidates)", 3: "candidate tiles"}
+names = {1: "S (survivors of phase A, fused-rule points)", 2: "nA (near candidates)", 3: "candidate tiles", 5: "remainder points alive after the filter"}
 for n, label in names.items():
     lib = os.path.join(ROOT, "rustsasa_amd", "lib", "variants", f"stat{n}", "librustsasa_amd.so")
     if os.path.exists(lib):
