@@ -419,6 +419,33 @@ def test_small_inputs_on_the_matrix_core_kernel(monkeypatch):
                 assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, w)), (w, n_points)
 
 
+@pytest.mark.parametrize("n_points,simd_width", [(35, 8), (63, 4), (66, 16), (70, 4), (83, 16), (97, 8), (99, 16), (100, 8), (100, 16),
+                                                 (103, 4), (115, 16), (122, 8), (127, 4), (113, 16)])
+def test_remainder_points_have_an_exact_pass_of_their_own(monkeypatch, n_points, simd_width):
+    """k_occlusion_mx, at most 128 points: the remainder points (the last n_points % W, lib.rs:163-218: plain products, `<=`) the
+    filter leaves alive are tested apart, exactly (phase_b_rem) - wherever they sit: among the first 64 points (35 / 8, 63 / 4:
+    lanes of the filter's first result), at the start of the second 64 (66 / 16), in any of its rows (83, 97-103, 113-127), one to
+    four of them, with 6, 7 and 8 tiles of points.  Every atom against the oracle run with the same lane count; the general
+    kernel gets nothing because of them."""
+    import rustsasa_amd
+    assert 0 < n_points % simd_width <= 4
+    monkeypatch.setenv("RSASA_OCCLUSION_KERNEL", "5")
+    for name in ("example.cif", "1jcd.pdb"):
+        xyz, r, _, ids = bw.fixture_soa(name)
+        x, y, z = (np.ascontiguousarray(xyz[:, k]).astype(np.float32) for k in range(3))
+        with rustsasa_amd.Context(0, simd_width=simd_width) as c:
+            got = c.calculate_sasa_soa(x, y, z, r, ids, PROBE, n_points)
+            want = po.calculate_sasa_internal(x, y, z, r, ids, PROBE, n_points, simd_width)
+            assert np.array_equal(got, want), (name, n_points, simd_width, int((got != want).sum()))
+            # (the same atoms without ids, timed: nothing is left to the general kernel - before round 6 a remainder point
+            # inside the matrix rounds' certainty band was)
+            c.enable_timing(True)
+            got = c.calculate_sasa_soa(x, y, z, r, None, PROBE, n_points)
+            assert c.timings()["n_deferred"] == 0
+            c.enable_timing(False)
+            assert np.array_equal(got, po.calculate_sasa_internal(x, y, z, r, None, PROBE, n_points, simd_width))
+
+
 def test_patch_test_of_the_many_point_kernel_on_cap_boundaries(monkeypatch):
     """More than 128 points: whole tiles of 16 points (compact patches of the sphere) are dropped when ONE near
     candidate's cap holds the patch (occlusion_mx.inc, patch test).  Caps of every size - a neighbour at distances
