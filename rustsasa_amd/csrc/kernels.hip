@@ -158,16 +158,32 @@ __global__ __launch_bounds__(THREADS) void k_ids_distinct(BatchView b)
         }
     };
     bool equal = false;
-    for (uint32_t i = threadIdx.x; i < n && !equal; i += THREADS) {
-        const uint64_t mine = load_id(b.id, b.id32, a0 + i);
-        uint32_t h = (uint32_t)(((uint64_t)(fold_id(mine) * 0x9E3779B1u) * SLOTS) >> 32);
-        for (;;) {
-            const uint32_t there = take(h, i + 1u);
-            if (there == 0u) break;
-            // (an entry is the number of one of this structure's atoms - anything else would count as an equal pair,
-            // never as an address)
-            if (there > n || load_id(b.id, b.id32, a0 + there - 1u) == mine) { equal = true; break; }
-            h = h + 1u == SLOTS ? 0u : h + 1u;
+    // (a thread's next kAhead ids are requested together: one memory round trip per kAhead atoms instead of one per atom; the
+    // large table's launch over the real-coordinates batch - 1 200 structures above 4 096 atoms, one workgroup per CU at a time -
+    // 173 -> 158 us.  A medium table of 48 KB for the structures of up to 12 288 atoms, three workgroups per CU, was no better:
+    // 133 us behind the large table's 100, one after the other on the stream - an insert costs what its probes' id loads cost)
+    constexpr uint32_t kAhead = LARGE ? 8u : 4u;
+    for (uint32_t i0 = threadIdx.x; i0 < n && !equal; i0 += THREADS * kAhead) {
+        uint64_t ahead[kAhead];
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; u++) {
+            const uint32_t i = i0 + u * THREADS;
+            ahead[u] = i < n ? load_id(b.id, b.id32, a0 + i) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kAhead; u++) {
+            const uint32_t i = i0 + u * THREADS;
+            if (i >= n || equal) break;
+            const uint64_t mine = ahead[u];
+            uint32_t h = (uint32_t)(((uint64_t)(fold_id(mine) * 0x9E3779B1u) * SLOTS) >> 32);
+            for (;;) {
+                const uint32_t there = take(h, i + 1u);
+                if (there == 0u) break;
+                // (an entry is the number of one of this structure's atoms - anything else would count as an equal pair,
+                // never as an address)
+                if (there > n || load_id(b.id, b.id32, a0 + there - 1u) == mine) { equal = true; break; }
+                h = h + 1u == SLOTS ? 0u : h + 1u;
+            }
         }
     }
     if (equal && (atomicOr(&b.grids[s].odd_radii, 2u) & 2u) == 0u) atomicAdd(&b.status->ids_needed, 1u);  // (once per structure)
