@@ -106,8 +106,9 @@ struct Combiner {
         const uint64_t b = batches.load(), c = std::max<uint64_t>(calls.load(), 1);
         if (b && tuning_env("RSASA_COMBINE_TRACE"))
             std::fprintf(stderr, "call combining: %llu batches, %.2f calls each; per batch us: leader waited %.1f for a lane, %.1f for the last copy-in, "
-                         "header + kernels %.1f; per call us: copy-in %.1f, whole call %.1f\n", (unsigned long long)b, (double)c / (double)b,
-                         ns_lane.load() / 1e3 / b, ns_close.load() / 1e3 / b, ns_run.load() / 1e3 / b, ns_copy_in.load() / 1e3 / c, ns_call.load() / 1e3 / c);
+                         "header + kernels %.1f (of it: header written and launches queued %.1f, waited for the stream %.1f); per call us: copy-in %.1f, whole call %.1f\n", (unsigned long long)b, (double)c / (double)b,
+                         ns_lane.load() / 1e3 / b, ns_close.load() / 1e3 / b, ns_run.load() / 1e3 / b, g_small_trace_ns[0].load() / 1e3 / b, g_small_trace_ns[1].load() / 1e3 / b,
+                         ns_copy_in.load() / 1e3 / c, ns_call.load() / 1e3 / c);
     }
 };
 Combiner g_combine[64];

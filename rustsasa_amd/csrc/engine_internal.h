@@ -525,6 +525,7 @@ SmallLayout small_layout(size_t S, size_t N, size_t W, size_t R, bool has_id, un
 int small_reserve(rsasa_context *ctx, const SmallLayout &l, const Lattice &lat, bool own_staging);
 int small_run(rsasa_context *ctx, const SmallLayout &l, const Lattice &lat, const StructGrid *grids, const uint4 *windows, char *h, char *hout,
               const void *records);
+extern std::atomic<uint64_t> g_small_trace_ns[2];
 void small_fill_records(const SmallSource &src, uint32_t begin, uint32_t end, rsasa_atom_t *recs, size_t at);
 int run_small_host_batch(rsasa_context *ctx, const SmallSource &in, const uint32_t *so, size_t S, float probe, size_t n_points,
                          float *out_atom, const uint32_t *ro, size_t R, float *out_res);

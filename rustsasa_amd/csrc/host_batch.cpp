@@ -112,6 +112,8 @@ void small_fill_records(const SmallSource &src, uint32_t begin, uint32_t end, rs
     }
 }
 
+std::atomic<uint64_t> g_small_trace_ns[2];  // merged batches: header + launches queued | waited for (combine.cpp prints them)
+
 // staging layout (16-byte aligned sections): status | grids | windows | x | y | z | r | id | residue offsets; results behind
 SmallLayout small_layout(size_t S, size_t N, size_t W, size_t R, bool has_id, unsigned long long total_cells16)
 {
@@ -166,6 +168,7 @@ int small_run(rsasa_context *ctx, const SmallLayout &l, const Lattice &lat, cons
               const void *records)
 {
     const bool zero_copy = records != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     const size_t S = l.S, N = l.N, W = l.W, R = l.R;
     BatchStatus stt{};
     stt.total_cells = l.tail_begin;
@@ -228,7 +231,13 @@ int small_run(rsasa_context *ctx, const SmallLayout &l, const Lattice &lat, cons
     launch_residue_sums(v, st);
     if (!single && !zero_copy) RS_HIP(ctx, hipMemcpyAsync(hout, dout, l.out_bytes, hipMemcpyDeviceToHost, st));
     RS_HIP(ctx, hipGetLastError());
+    const auto t_queued = std::chrono::steady_clock::now();
     RS_HIP(ctx, hipStreamSynchronize(st));
+    if (zero_copy) {  // (RSASA_COMBINE_TRACE: a merged batch's launches against the wait for them; two relaxed adds otherwise)
+        const auto t_done = std::chrono::steady_clock::now();
+        g_small_trace_ns[0].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_queued - t_begin).count(), std::memory_order_relaxed);
+        g_small_trace_ns[1].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t_done - t_queued).count(), std::memory_order_relaxed);
+    }
     if ((single || zero_copy) && *flag) {
         launch_occlusion_deferred(v, lat, st);
         launch_residue_sums(v, st);
